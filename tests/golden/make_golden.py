@@ -1,0 +1,515 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the *imported reference*.
+
+Run ONLY in the development container, where /root/reference exists:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (nordmtr/quantpy, pure Python) is imported read-only from
+/root/reference.  `quantpy/__init__.py` pulls in `tomography/interval.py`, which imports
+`cvxopt` at module level for SOCP/LP interval classes that are NOT on the hot path; cvxopt
+is not installed and there is no network, so an inert in-process placeholder module is
+registered for that one import.  Nothing under /root/reference is
+written to, and nothing of the reference is copied: the outputs are numeric input/output
+vectors only (npz / json), which is what travels to the GPU box.
+
+Versions recorded in golden/meta.json (reference pins: python 3.9 / numpy 1.23.4 /
+scipy 1.9.3; oracle container: see meta.json).
+"""
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import scipy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _import_reference():
+    placeholder = types.ModuleType("cvxopt")
+    placeholder.matrix = lambda *a, **k: None
+    placeholder.solvers = types.SimpleNamespace(options={})
+    sys.modules["cvxopt"] = placeholder
+    sys.path.insert(0, REF)
+    import quantpy as qp  # noqa
+
+    return qp
+
+
+qp = _import_reference()
+import quantpy.tomography.state as ref_state  # noqa: E402
+from quantpy.routines import (  # noqa: E402
+    _left_inv,
+    _matrix_to_real_tril_vec,
+    _real_tril_vec_to_matrix,
+    generate_pauli,
+)
+from scipy.optimize import minimize as _scipy_minimize  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+# --------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------
+
+
+def ginibre_state(rng, d, rank=None):
+    """rho = G G^dagger / Tr, G (d, rank) complex standard normal."""
+    r = d if rank is None else rank
+    g = rng.standard_normal((d, r)) + 1j * rng.standard_normal((d, r))
+    rho = g @ g.conj().T
+    return rho / np.trace(rho)
+
+
+_CAPTURE = {}
+
+
+def _recording_minimize(fun, x0, *args, **kwargs):
+    """Wrap scipy.optimize.minimize as called at reference state.py:213 and record the
+    OptimizeResult plus the per-iteration iterates (return_all) without changing what
+    the reference computes."""
+    opts = dict(kwargs.get("options", {}))
+    if kwargs.get("method") == "BFGS":
+        opts["return_all"] = True
+    kwargs["options"] = opts
+    res = _scipy_minimize(fun, x0, *args, **kwargs)
+    _CAPTURE["res"] = res
+    _CAPTURE["x0"] = np.array(x0, dtype=float)
+    return res
+
+
+ref_state.minimize = _recording_minimize
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# --------------------------------------------------------------------------------------
+# a1/a2: Pauli bases and POVM tensors
+# --------------------------------------------------------------------------------------
+def gen_operators():
+    out = {}
+    for n in (1, 2, 3):
+        out[f"pauli_n{n}"] = np.asarray(generate_pauli(n))
+        for povm in ("proj", "proj-set", "proj4", "sic"):
+            out[f"povm_{povm}_n{n}"] = qp.generate_measurement_matrix(povm, n)
+    # custom 1-qubit table (2-D and 3-D) expanded by kron
+    tab = np.array([[0.5, 0.1, 0.2, 0.3], [0.5, -0.1, -0.2, -0.3]])
+    out["povm_custom2d_in"] = tab
+    out["povm_custom2d_n2"] = qp.generate_measurement_matrix(tab, 2)
+    # n = 4, 5 'proj-set': shape + 64 sampled entries (full tensor is 63.7 MB at n=5)
+    rng = np.random.default_rng(5)
+    for n in (4, 5):
+        A = qp.generate_measurement_matrix("proj-set", n)
+        idx = np.stack([rng.integers(0, s, 64) for s in A.shape], axis=1)
+        out[f"povm_proj-set_n{n}_shape"] = np.array(A.shape)
+        out[f"povm_proj-set_n{n}_idx"] = idx
+        out[f"povm_proj-set_n{n}_val"] = A[idx[:, 0], idx[:, 1], idx[:, 2]]
+        out[f"povm_proj-set_n{n}_sum"] = np.array([A.sum(), np.abs(A).sum()])
+    save("operators", **out)
+
+
+# --------------------------------------------------------------------------------------
+# a3/a4: Bloch <-> matrix, Born probabilities
+# --------------------------------------------------------------------------------------
+def gen_states_and_born():
+    out = {}
+    rng = np.random.default_rng(2024)
+    for n in (1, 2, 3, 4):
+        d = 2**n
+        rhos = np.stack([ginibre_state(rng, d, rank=(None if i % 2 == 0 else 1)) for i in range(6)])
+        blochs = np.stack([qp.Qobj(r).bloch for r in rhos])
+        back = np.stack([qp.Qobj(b).matrix for b in blochs])
+        out[f"rho_n{n}"] = rhos
+        out[f"bloch_n{n}"] = blochs
+        out[f"rho_from_bloch_n{n}"] = back
+        # a non-Hermitian matrix: the reference keeps Re Tr(P_k M^dagger)/d  (qobj.py:132)
+        m = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        out[f"nonherm_n{n}"] = m
+        out[f"nonherm_bloch_n{n}"] = qp.Qobj(m).bloch
+        if n <= 3:
+            for povm in ("proj", "proj-set", "sic"):
+                A = qp.generate_measurement_matrix(povm, n)
+                p = np.stack([np.einsum("ijk,k->ij", A, b) * d for b in blochs])
+                out[f"born_{povm}_n{n}"] = p
+    save("states_born", **out)
+
+
+# --------------------------------------------------------------------------------------
+# a4: counts (pins the legacy RNG call order), a6/a7: linear inversion
+# --------------------------------------------------------------------------------------
+def gen_counts_lin():
+    out = {}
+    # C1: |0>, 10 000 shots / setting, seed 0
+    np.random.seed(0)
+    t = qp.StateTomograph(qp.qobj.zero(1))
+    t.experiment(10000)
+    out["C1_counts"] = t.results
+    out["C1_n_meas"] = t.n_measurements
+    out["C1_lin"] = t.point_estimate("lin").matrix
+    out["C1_lin_unphys"] = t.point_estimate("lin", physical=False).matrix
+    out["C1_lin_bloch_unphys"] = t.point_estimate("lin", physical=False).bloch
+    out["C1_mle"] = t.point_estimate("mle").matrix
+
+    # C2: Ginibre rho (rng 1234), seed 7, 100 000 shots / setting, 8 consecutive trials
+    rng = np.random.default_rng(1234)
+    rho = ginibre_state(rng, 8)
+    out["C2_rho_true"] = rho
+    np.random.seed(7)
+    t = qp.StateTomograph(qp.Qobj(rho))
+    counts, lin, lin_u, mle, nit, nfev = [], [], [], [], [], []
+    for _ in range(8):
+        t.experiment(100000, "proj-set")
+        counts.append(t.results.copy())
+        lin_u.append(t.point_estimate("lin", physical=False).matrix)
+        lin.append(t.point_estimate("lin").matrix)
+        mle.append(t.point_estimate("mle").matrix)
+        nit.append(_CAPTURE["res"].nit)
+        nfev.append(_CAPTURE["res"].nfev)
+    out["C2_counts"] = np.stack(counts)
+    out["C2_lin"] = np.stack(lin)
+    out["C2_lin_unphys"] = np.stack(lin_u)
+    out["C2_mle"] = np.stack(mle)
+    out["C2_nit"] = np.array(nit)
+    out["C2_nfev"] = np.array(nfev)
+
+    # per-setting shot vector + other POVMs + n = 1, 2 (ragged N_s exercises the weights)
+    rng = np.random.default_rng(99)
+    k = 0
+    for n, povm, nm in (
+        (1, "proj-set", np.array([100, 2000, 30000])),
+        (2, "proj-set", 5000),
+        (2, "proj", 20000),
+        (2, "sic", 20000),
+        (3, "proj", 200000),
+        (3, "sic", 50000),
+        (3, "proj-set", 1000),
+    ):
+        rho = ginibre_state(rng, 2**n)
+        np.random.seed(100 + k)
+        t = qp.StateTomograph(qp.Qobj(rho))
+        t.experiment(nm, povm)
+        key = f"L{k}"
+        out[key + "_n"] = np.array(n)
+        out[key + "_povm"] = np.array(povm)
+        out[key + "_seed"] = np.array(100 + k)
+        out[key + "_rho_true"] = rho
+        out[key + "_nmeas_arg"] = np.asarray(nm)
+        out[key + "_counts"] = t.results
+        out[key + "_povm_matrix"] = t.povm_matrix
+        A = np.reshape(
+            t.povm_matrix * t.n_measurements[:, None, None] / np.sum(t.n_measurements),
+            (-1, t.povm_matrix.shape[-1]),
+        )
+        out[key + "_leftinv"] = _left_inv(A)
+        r_u = t.point_estimate("lin", physical=False)
+        out[key + "_lin_unphys"] = r_u.matrix
+        out[key + "_lin_bloch"] = r_u.bloch
+        out[key + "_lin_eigs"] = np.linalg.eigvalsh(r_u.matrix)
+        out[key + "_lin"] = t.point_estimate("lin").matrix
+        k += 1
+    out["n_lin_cases"] = np.array(k)
+    save("counts_lin", **out)
+
+
+# --------------------------------------------------------------------------------------
+# a8/a9: Cholesky parametrisation, NLL, finite-difference gradient as SciPy forms it
+# --------------------------------------------------------------------------------------
+def gen_chol_nll():
+    from scipy.optimize._numdiff import approx_derivative
+
+    out = {}
+    rng = np.random.default_rng(31)
+    k = 0
+    for n in (1, 2, 3):
+        d = 2**n
+        for povm, shots in (("proj-set", 100000), ("proj", 300), ("sic", 1000)):
+            rho = ginibre_state(rng, d)
+            np.random.seed(500 + k)
+            t = qp.StateTomograph(qp.Qobj(rho))
+            t.experiment(shots, povm)
+            x = _matrix_to_real_tril_vec(rho)
+            xr = x + 0.05 * rng.standard_normal(x.shape)  # a generic (unnormalised) point
+            key = f"N{k}"
+            out[key + "_n"] = np.array(n)
+            out[key + "_counts"] = t.results
+            out[key + "_povm_matrix"] = t.povm_matrix
+            out[key + "_rho"] = rho
+            out[key + "_x"] = x
+            out[key + "_LLh"] = _real_tril_vec_to_matrix(x)
+            out[key + "_xr"] = xr
+            out[key + "_LLh_r"] = _real_tril_vec_to_matrix(xr)
+            out[key + "_nll_x"] = np.array(t._nll(x))
+            out[key + "_nll_xr"] = np.array(t._nll(xr))
+            # SciPy's BFGS gradient: 2-point, absolute step sqrt(eps)  (optimize/_optimize.py)
+            eps = np.sqrt(np.finfo(float).eps)
+            out[key + "_fdgrad_xr"] = approx_derivative(t._nll, xr, method="2-point", abs_step=eps)
+            out[key + "_cgrad_xr"] = approx_derivative(t._nll, xr, method="3-point", abs_step=1e-6)
+            k += 1
+    out["n_nll_cases"] = np.array(k)
+    save("chol_nll", **out)
+
+
+# --------------------------------------------------------------------------------------
+# a10: MLE (BFGS) trials incl. iterating ones, with the optimizer trajectory
+# --------------------------------------------------------------------------------------
+def gen_mle():
+    out = {}
+    rng = np.random.default_rng(77)
+    cases = []
+    for n in (1, 2, 3):
+        d = 2**n
+        full = ginibre_state(rng, d)
+        rank1 = ginibre_state(rng, d, rank=1)
+        rank2 = ginibre_state(rng, d, rank=min(2, d))
+        zero = qp.qobj.zero(n).matrix
+        mixed = qp.qobj.fully_mixed(n).matrix
+        named = [("full", full), ("rank1", rank1), ("zero", zero), ("mixed", mixed)]
+        if n >= 2:
+            named.append(("ghz", qp.qobj.GHZ(n).matrix))
+            named.append(("rank2", rank2))
+        for name, rho in named:
+            for shots in (100, 100000):
+                for init in ("lin", "mixed"):
+                    cases.append((n, name, rho, shots, init, "proj-set"))
+        cases.append((n, "full", full, 1000, "lin", "proj"))
+        cases.append((n, "rank1", rank1, 1000, "lin", "sic"))
+    k = 0
+    for n, name, rho, shots, init, povm in cases:
+        np.random.seed(1000 + k)
+        t = qp.StateTomograph(qp.Qobj(rho))
+        t.experiment(shots, povm)
+        key = f"M{k}"
+        out[key + "_n"] = np.array(n)
+        out[key + "_name"] = np.array(name)
+        out[key + "_init"] = np.array(init)
+        out[key + "_povm"] = np.array(povm)
+        out[key + "_shots"] = np.array(shots)
+        out[key + "_seed"] = np.array(1000 + k)
+        out[key + "_rho_true"] = rho
+        out[key + "_counts"] = t.results
+        _CAPTURE.clear()
+        try:
+            r = t.point_estimate("mle", init=init)
+            res = _CAPTURE["res"]
+            out[key + "_rho"] = r.matrix
+            out[key + "_ok"] = np.array(1)
+            out[key + "_x0"] = _CAPTURE["x0"]
+            out[key + "_xfinal"] = res.x
+            out[key + "_fun"] = np.array(res.fun)
+            out[key + "_jac"] = res.jac
+            out[key + "_nit"] = np.array(res.nit)
+            out[key + "_nfev"] = np.array(res.nfev)
+            out[key + "_njev"] = np.array(res.njev)
+            out[key + "_status"] = np.array(res.status)
+            av = np.asarray(res.allvecs)
+            out[key + "_allvecs"] = av
+            out[key + "_fvals"] = np.array([t._nll(v) for v in av])
+            print(f"   M{k}: n={n} {name:6s} shots={shots:6d} init={init:5s} {povm:8s} "
+                  f"nit={res.nit} nfev={res.nfev} status={res.status}")
+        except Exception as e:  # e.g. LinAlgError from la.cholesky (routines.py:86)
+            out[key + "_ok"] = np.array(0)
+            out[key + "_error"] = np.array(type(e).__name__)
+            print(f"   M{k}: n={n} {name} shots={shots} init={init}: {type(e).__name__}: {e}")
+        k += 1
+    out["n_mle_cases"] = np.array(k)
+    save("mle", **out)
+
+
+# --------------------------------------------------------------------------------------
+# a11-a15: process tomography (C3, n=1 cases, notebook known answer)
+# --------------------------------------------------------------------------------------
+def gen_process():
+    out = {}
+    # --- notebook known answer (notebooks/Moments.ipynb cells 3, 5, 6, 7; input.json:18-23)
+    s = 0.2886751345948129
+    s4 = 0.28867513459481287
+    sic_states = [[0.5, s, s, s4], [0.5, s, -s, -s4], [0.5, -s, s, -s4], [0.5, -s, -s, s4]]
+    target = [0.5, 0, 0, 0, 0, 0, 0, 0.5, 0, 0, 0.5, 0, 0, 0.5, 0, 0]
+    counts = np.array(json.load(open(os.path.join(REF, "input.json")))["outcomes"])
+    tmg = qp.ProcessTomograph(qp.Channel(qp.Qobj(target)), input_states=[qp.Qobj(b) for b in sic_states])
+    np.random.seed(0)
+    tmg.experiment(10000, "proj-set")
+    tmg.results = counts
+    ch = tmg.point_estimate(cptp=False)
+    out["NB_input_blochs"] = np.array(sic_states)
+    out["NB_counts"] = counts
+    out["NB_choi_nocptp"] = ch.choi.matrix
+    out["NB_choi_bloch_nocptp"] = ch.choi.bloch
+    out["NB_lifp_oper"] = tmg._lifp_oper
+    out["NB_lifp_oper_inv"] = tmg._lifp_oper_inv
+    out["NB_choi_cptp"] = tmg.point_estimate(cptp=True).choi.matrix
+    # values printed in the notebook itself (Moments.ipynb cell 6 / cell 7 outputs)
+    out["NB_printed_bloch_nocptp"] = np.array(
+        [5.00000000e-01, 1.20000000e-03, 1.27500000e-03, 2.47500000e-03,
+         -2.77555756e-17, -3.63730670e-03, -1.42894192e-03, 5.05109317e-01,
+         0.00000000e+00, -6.49519053e-03, 5.01818420e-01, 8.87676039e-03,
+         5.55111512e-17, 4.96665569e-01, -4.33012702e-05, 4.54663337e-03])
+    out["NB_printed_choi_cptp"] = np.array(
+        [[0.50321637 + 0.0j, 0.49729217 + 2.15697599e-03j, 0.49706507 + 2.56306202e-03j, -0.50099188 - 4.82421850e-03j],
+         [0.49729217 - 2.15697599e-03j, 0.49678363 - 2.16840434e-19j, 0.49479818 + 2.48192079e-03j, -0.49706507 - 2.56306202e-03j],
+         [0.49706507 - 2.56306202e-03j, 0.49479818 - 2.48192079e-03j, 0.49856023 + 0.0j, -0.49742196 - 2.79553158e-03j],
+         [-0.50099188 + 4.82421850e-03j, -0.49706507 + 2.56306202e-03j, -0.49742196 + 2.79553158e-03j, 0.50143977 + 0.0j]])
+
+    # --- generic cases: (n, channel builder, shots, povm, seed)
+    def dyk_iters(tmg_, choi_vec):
+        """count Dykstra iterations the way process.py:243-256 stops."""
+        import scipy.linalg as la
+        from quantpy.routines import _vec2mat
+
+        x = choi_vec.copy()
+        p = q = y = 0
+        for i in range(1000):
+            crit = 0
+            y_diff = tmg_.tp_projection(qp.Channel(_vec2mat(x + p)), vectorized=True) - y
+            y = y + y_diff
+            x_diff = tmg_.cp_projection(qp.Channel(_vec2mat(y + q)), vectorized=True) - x
+            x = x + x_diff
+            crit += 2 * (np.abs(np.sum(y_diff.T.conj() * q)) + np.abs(np.sum(x_diff.T.conj() * p)))
+            p_diff = x - y
+            p = p + p_diff
+            q_diff = y - x
+            q = q + q_diff
+            crit += la.norm(p_diff) ** 2 + la.norm(q_diff) ** 2
+            if crit < 1e-12:
+                break
+        return i + 1
+
+    from quantpy.routines import _mat2vec
+
+    cases = [
+        ("P0", 1, lambda: qp.channel.depolarizing(0.1, 1), 10000, "proj-set", 11),
+        ("P1", 1, lambda: qp.operator.H.as_channel(), 1000, "proj-set", 12),
+        ("P2", 1, lambda: qp.channel.amplitude_damping(0.3), 5000, "sic", 13),
+        ("C3", 2, lambda: qp.channel.depolarizing(0.1, 2), 10000, "proj-set", 11),
+        ("P4", 2, lambda: qp.operator.CNOT.as_channel(), 1000, "proj-set", 14),
+    ]
+    for key, n, mk, shots, povm, seed in cases:
+        np.random.seed(seed)
+        tmg = qp.ProcessTomograph(mk())
+        tmg.experiment(shots, povm)
+        out[key + "_n"] = np.array(n)
+        out[key + "_seed"] = np.array(seed)
+        out[key + "_shots"] = np.array(shots)
+        out[key + "_povm"] = np.array(povm)
+        out[key + "_true_choi"] = tmg.channel.choi.matrix
+        out[key + "_input_states"] = np.stack([s_.matrix for s_ in tmg.input_basis.elements])
+        out[key + "_output_states"] = np.stack([t_.state.matrix for t_ in tmg.tomographs])
+        out[key + "_counts"] = tmg.results
+        ch = tmg.point_estimate("lifp", cptp=False)
+        out[key + "_choi_nocptp"] = ch.choi.matrix
+        if n == 1:
+            out[key + "_lifp_oper"] = tmg._lifp_oper
+            out[key + "_lifp_oper_inv"] = tmg._lifp_oper_inv
+        else:
+            # 576 x 256 complex: keep a strided sample + checksum (full = 2.4 MB x 2)
+            out[key + "_lifp_oper_rows"] = tmg._lifp_oper[::37]
+            out[key + "_lifp_oper_inv_cols"] = tmg._lifp_oper_inv[:, ::37]
+            out[key + "_lifp_oper_abs_sum"] = np.array(np.abs(tmg._lifp_oper).sum())
+        out[key + "_dykstra_iters"] = np.array(dyk_iters(tmg, _mat2vec(ch.choi.matrix)))
+        out[key + "_choi_cptp"] = tmg.point_estimate("lifp", cptp=True).choi.matrix
+        out[key + "_tp_only"] = tmg.tp_projection(ch).choi.matrix
+        out[key + "_cp_only"] = tmg.cp_projection(ch).choi.matrix
+        print(f"   {key}: n={n} dykstra iters={int(out[key + '_dykstra_iters'])}")
+    save("process", **out)
+
+
+# --------------------------------------------------------------------------------------
+# a16: bootstrap (small): counts per resample, distances, quantiles
+# --------------------------------------------------------------------------------------
+def gen_bootstrap():
+    out = {}
+    rng = np.random.default_rng(1234)
+    rho = ginibre_state(rng, 8)
+    for tag, n, method, n_points, shots in (("B3lin", 3, "lin", 64, 100000), ("B3mle", 3, "mle", 24, 100000),
+                                             ("B1mle", 1, "mle", 40, 1000), ("B2mle", 2, "mle", 24, 200)):
+        if n == 3:
+            state = qp.Qobj(rho)
+        else:
+            state = qp.Qobj(ginibre_state(np.random.default_rng(50 + n), 2**n))
+        np.random.seed(7)
+        t = qp.StateTomograph(state)
+        t.experiment(shots, "proj-set")
+        centre = t.point_estimate(method)
+        out[tag + "_true"] = state.matrix
+        out[tag + "_counts0"] = t.results
+        out[tag + "_centre"] = centre.matrix
+        # replay of interval.py:598-609 that also records each resample's counts
+        np.random.seed(4242)
+        boot = qp.StateTomograph(centre, t.dst)
+        cs, ds, rs = [], [], []
+        for _ in range(n_points):
+            boot.experiment(t.n_measurements, t.povm_matrix)
+            r = boot.point_estimate(method=method)
+            cs.append(boot.results.copy())
+            rs.append(r.matrix)
+            ds.append(t.dst(r, centre))
+        # and the reference class itself on the same RNG stream: must agree with the replay
+        np.random.seed(4242)
+        iv = qp.BootstrapStateInterval(t, n_points=n_points, method=method)
+        dist, cl = iv([0.5, 0.9, 0.95])
+        assert np.allclose(np.sort(ds), np.sort(iv.cl_to_dist.y), rtol=0, atol=0), "replay differs"
+        out[tag + "_boot_counts"] = np.stack(cs)
+        out[tag + "_boot_rho"] = np.stack(rs)
+        out[tag + "_boot_dist"] = np.array(ds)
+        out[tag + "_cl"] = np.array(cl)
+        out[tag + "_cl_dist"] = np.array(dist)
+        out[tag + "_nmeas"] = t.n_measurements
+        print(f"   {tag}: quantiles {dist}")
+    save("bootstrap", **out)
+
+
+# --------------------------------------------------------------------------------------
+# n = 4, 5: 'lin' and one NLL value (full MLE is infeasible in the reference: SURVEY 6.2)
+# --------------------------------------------------------------------------------------
+def gen_large():
+    out = {}
+    for n, shots in ((4, 100000), (5, 1000000)):
+        rng = np.random.default_rng(1234 + n)
+        rho = ginibre_state(rng, 2**n)
+        np.random.seed(7)
+        t = qp.StateTomograph(qp.Qobj(rho))
+        t.experiment(shots, "proj-set")
+        out[f"n{n}_rho_true"] = rho
+        out[f"n{n}_counts"] = t.results
+        out[f"n{n}_lin_unphys"] = t.point_estimate("lin", physical=False).matrix
+        lin = t.point_estimate("lin").matrix
+        out[f"n{n}_lin"] = lin
+        x = _matrix_to_real_tril_vec(lin)
+        out[f"n{n}_x"] = x
+        out[f"n{n}_nll"] = np.array(t._nll(x))
+        print(f"   n={n}: nll={float(out[f'n{n}_nll']):.12f}")
+    save("large", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "bootstrap", "large"]
+    table = {
+        "operators": gen_operators,
+        "states": gen_states_and_born,
+        "counts": gen_counts_lin,
+        "chol": gen_chol_nll,
+        "mle": gen_mle,
+        "process": gen_process,
+        "bootstrap": gen_bootstrap,
+        "large": gen_large,
+    }
+    for w in which:
+        print(f"[{w}]")
+        table[w]()
+    meta = {
+        "generated_by": "tests/golden/make_golden.py (imports /root/reference read-only)",
+        "python": sys.version.split()[0],
+        "numpy": np.__version__,
+        "scipy": scipy.__version__,
+        "reference_pins": {"python": "^3.9,<3.10", "numpy": "1.23.4", "scipy": "1.9.3"},
+    }
+    with open(os.path.join(HERE, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)

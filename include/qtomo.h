@@ -1,0 +1,142 @@
+/* qtomo.h -- C ABI of libqtomo.so, the MI355X (gfx950) tomography-reconstruction engine.
+ *
+ * The reference (nordmtr/quantpy) is pure Python and has no FFI; this boundary sits directly
+ * beneath the reference methods cited on each entry point (paths are into the reference tree,
+ * SURVEY.md section 8a/8b).  INTEGRATION.md shows the ctypes binding a quantpy maintainer would
+ * add; quantpy_amd/_capi.py is that binding for this repository's drop-in classes.
+ *
+ * Conventions
+ *   - n qubits, d = 2^n, D = 4^n; a POVM is a tensor A[S][K][D] of Bloch rows (M = S*K rows).
+ *   - all arrays are caller-owned and C-contiguous; complex = interleaved double[2] (re, im).
+ *   - pointers are HOST pointers unless `flags & QT_DEVICE_PTR`, in which case every array
+ *     argument of that call is a device pointer valid on the handle's device and the call is
+ *     asynchronous on the handle's stream (qt_sync to wait).
+ *   - every function returns 0 on success and a negative qt_status on argument / runtime errors
+ *     (qt_last_error() gives the text).  Batched estimators additionally fill a per-trial
+ *     `int32 status[B]` with qt_trial_status and, for host-pointer calls, return the number of
+ *     trials whose status is non-zero.
+ *   - a handle is bound to one device and one stream and is not thread-safe; use one handle per
+ *     host thread.  No exception crosses the ABI.  There is no CPU fallback: without a usable
+ *     HIP device qt_create fails.
+ */
+#ifndef QTOMO_H
+#define QTOMO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qt_handle qt_handle_t;
+
+enum qt_status {
+  QT_OK = 0,
+  QT_ERR_ARG = -1,      /* bad argument (null pointer, size, n_qubits out of range) */
+  QT_ERR_STATE = -2,    /* call order: e.g. estimator before qt_set_povm */
+  QT_ERR_HIP = -3,      /* HIP runtime error */
+  QT_ERR_SINGULAR = -4, /* A^T A is singular: the POVM is not informationally complete */
+  QT_ERR_UNSUPPORTED = -5
+};
+
+enum qt_trial_status {
+  QT_TRIAL_OK = 0,
+  QT_TRIAL_NOT_PD = 1,      /* Cholesky pivot <= 0: scipy.linalg.cholesky raises LinAlgError   */
+  QT_TRIAL_LINESEARCH = 2,  /* both line searches failed: scipy BFGS warnflag 2                 */
+  QT_TRIAL_MAXITER = 3,     /* iteration cap reached: scipy BFGS warnflag 1                     */
+  QT_TRIAL_NAN = 4          /* NaN in value, gradient or parameters: scipy BFGS warnflag 3      */
+};
+
+enum qt_flags { QT_HOST_PTR = 0, QT_DEVICE_PTR = 1 };
+enum qt_init { QT_INIT_LIN = 0, QT_INIT_MIXED = 1 };
+
+/* ---- library / handle ------------------------------------------------------------------ */
+int qt_version(void);
+const char* qt_last_error(void);
+/* number of HIP devices visible, or a negative qt_status */
+int qt_device_count(void);
+/* n_qubits in 1..5 for operator assembly and conversions; estimators: 1..3 in this release */
+qt_handle_t* qt_create(int device, int n_qubits);
+void qt_destroy(qt_handle_t* h);
+int qt_sync(qt_handle_t* h);
+/* run the handle's work on an existing hipStream_t (e.g. torch's current stream); NULL = own */
+int qt_set_stream(qt_handle_t* h, void* hip_stream);
+/* hipEvent timers on the handle's stream: begin, ..., end -> elapsed milliseconds */
+int qt_timer_begin(qt_handle_t* h);
+int qt_timer_end(qt_handle_t* h, double* elapsed_ms);
+
+/* ---- a1: quantpy/routines.py:14-19 generate_pauli ---------------------------------------- */
+/* out[D][d][d][2]: P_k = P_k1 (x) ... (x) P_kn, k = sum_j k_j 4^(n-1-j) */
+int qt_pauli_basis(qt_handle_t* h, double* out, int flags);
+
+/* ---- a2: quantpy/measurements.py:88-93 generate_measurement_matrix (array / string path) - */
+/* povm1[S1][K1][4] one-qubit table -> out[S1^n][K1^n][D], all three axes Kronecker'd */
+int qt_povm_kron(qt_handle_t* h, const double* povm1, int S1, int K1, double* out, int flags);
+
+/* ---- a5 + cache: quantpy/routines.py:69-71 _left_inv; state.py:194-197, 222-225 ----------- */
+/* Stores A[S][K][D], the shot-weighted A' = A * Ns[s] / sum(Ns) reshaped (M, D), and the left
+ * inverse inv(A'^T A') A'^T (plain transpose).  Ns[S] = shots per setting (as float64, like the
+ * reference's n_measurements).  Every later estimator call on this handle uses this POVM and
+ * assumes each trial's per-setting totals equal Ns. */
+int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns, int flags);
+/* out[D][M]: the cached left inverse (for inspection / tests) */
+int qt_get_left_inverse(qt_handle_t* h, double* out, int flags);
+
+/* ---- a4: quantpy/tomography/state.py:109-110 (probabilities only; sampling stays on host) -- */
+/* p[B][S][K] = clip(d * sum_k A[s][k'][k] bloch[b][k], 0, 1) */
+int qt_born_probs(qt_handle_t* h, const double* bloch, int B, double* p, int flags);
+
+/* ---- a3: quantpy/qobj.py:109-135 + geometry.py:59-70 --------------------------------------- */
+/* bloch[b][k] = Re Tr(P_k M_b^dagger) / d ;  M_b = sum_k bloch[b][k] P_k */
+int qt_bloch_from_mat(qt_handle_t* h, const double* mat, int B, double* bloch, int flags);
+int qt_mat_from_bloch(qt_handle_t* h, const double* bloch, int B, double* mat, int flags);
+
+/* ---- a6 + a7: state.py:191-202 _point_estimate_lin, :267-273 _make_feasible ---------------- */
+/* counts[B][S][K] int64 -> rho[B][d][d][2].  physical != 0: eigenvalues clipped at 1e-15 and
+ * the trace renormalised.  bloch_out (nullable): the linear-inversion Bloch vector [B][D]. */
+int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, double* rho, double* bloch_out,
+                 int32_t* status, int flags);
+
+/* ---- a8: quantpy/routines.py:84-101 Cholesky parametrisation ------------------------------- */
+/* x[B][D] = [diag L | Re L_(i>j) | Im L_(i>j)] (strict lower in np.tril_indices order) of
+ * rho[B][d][d][2] = L L^dagger ; and back (LLh = L L^dagger, not normalised) */
+int qt_chol_param(qt_handle_t* h, const double* rho, int B, double* x, int32_t* status, int flags);
+int qt_chol_unparam(qt_handle_t* h, const double* x, int B, double* LLh, int flags);
+
+/* ---- a9: state.py:217-229 _nll (value) and its exact gradient ------------------------------ */
+/* f[b] = -sum_m freq_m log(d (A' b(x_b))_m + 1e-10), freq = counts / sum(counts);
+ * grad (nullable) [B][D] = df/dx (analytic; the reference differentiates numerically) */
+int qt_nll_batch(qt_handle_t* h, const double* x, const int64_t* counts, int B, double* f, double* grad, int flags);
+
+/* ---- a10: state.py:204-215 _point_estimate_mle_chol + scipy BFGS --------------------------- */
+/* tol is scipy's gtol (inf-norm of the gradient); max_iter its maxiter.  Outputs (each nullable
+ * except rho): nit[B] BFGS iterations, nfev[B] value+gradient evaluations (the reference's own
+ * nfev, which also counts its finite-difference probes, equals nfev * (D + 1)), fun[B] final
+ * objective, status[B]. */
+int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol, double* rho,
+                 int32_t* nit, int32_t* nfev, double* fun, int32_t* status, int flags);
+
+/* ---- a16: quantpy/geometry.py:5-20 hs_dst --------------------------------------------------- */
+/* dist[b] = sqrt(|Tr((rho_b - centre)^2)|) / sqrt(2), set to 0 below 1e-15 */
+int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, int B, double* dist, int flags);
+
+/* ---- a11-a15: quantpy/tomography/process.py -------------------------------------------------- */
+/* Process tomography of an n-qubit channel (handle created with n_qubits = n, n <= 2 here).
+ * qt_process_setup: input states in_states[D][d][d][2] (process.py:79), the weighted POVM of
+ * qt_set_povm (call it first) -> design matrix rows vec(rho_in (x) E_m^T) (process.py:203-208),
+ * its left inverse (process.py:210), and the partial-trace operator (routines.py:47-50). */
+int qt_process_setup(qt_handle_t* h, const double* in_states, int flags);
+/* lifp_oper[D*M][D^2][2] (nullable) and its left inverse [D^2][D*M][2] (nullable) */
+int qt_process_get_operators(qt_handle_t* h, double* lifp_oper, double* lifp_oper_inv, int flags);
+/* counts[B][D][S][K] -> choi[B][D][D][2] (process.py:284-289); cptp != 0 applies the Dykstra
+ * projection of process.py:231-257 (n_iter <= 1000, stop 1e-12); iters[B] (nullable) */
+int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double* choi, int32_t* iters,
+                  int32_t* status, int flags);
+/* projections alone (process.py:231-278): mode 0 = CPTP (Dykstra), 1 = TP, 2 = CP */
+int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode, int n_iter, double tol,
+                          double* choi_out, int32_t* iters, int flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QTOMO_H */

@@ -613,11 +613,13 @@ def _psd_sqrt(a):
 
 
 def infidelity(a, b):
-    """1 - (Tr sqrt(sqrt(A) B sqrt(A)))^2   (geometry.py:52) via eigh-based roots, which stay
-    accurate on singular matrices where scipy.linalg.sqrtm does not."""
-    s = _psd_sqrt(a)
-    v = la.eigvalsh(s @ b @ s)
-    return 1 - np.sum(np.sqrt(np.maximum(v, 0))) ** 2
+    """1 - (Tr sqrt(sqrt(A) B sqrt(A)))^2   (geometry.py:52), evaluated as the nuclear norm
+    1 - (sum of singular values of sqrt(A) sqrt(B))^2 with eigh-based roots.  The reference's
+    scipy.linalg.sqrtm is only ~1e-8 accurate on singular matrices, and taking
+    square roots of the eigenvalues of sqrt(A) B sqrt(A) turns 1e-17 rounding noise on a zero
+    eigenvalue into 3e-9; singular values carry no such amplification (error ~1e-15)."""
+    sv = la.svdvals(_psd_sqrt(a) @ _psd_sqrt(b))
+    return 1 - np.sum(sv) ** 2
 
 
 # --------------------------------------------------------------------------------------

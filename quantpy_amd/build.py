@@ -1,0 +1,38 @@
+"""Build libqtomo.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libqtomo.so")
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(_HERE), "include", "qtomo.h")]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -shared -fPIC csrc/qtomo.hip -> lib/libqtomo.so"""
+    if not force and not _stale():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB + ".tmp", os.path.join(CSRC, "qtomo.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB

@@ -1,0 +1,387 @@
+// Size-generic kernels (any n <= 5): operator assembly, POVM weighting, Gram / left inverse,
+// Born probabilities, matrix <-> Bloch conversion, Hilbert-Schmidt distance.
+// All are HBM/L2-streaming kernels: coalesced along the fastest axis, LDS tiles where an
+// operand is re-used.  Reference lines are cited per kernel (paths into /root/reference/quantpy).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qt {
+
+// ---- a1: routines.py:14-19 ----------------------------------------------------------------
+// out[k][r][c] = (c == r ^ x(k)) ? (-i)^ny(k) (-1)^popc(r & z(k)) : 0, one thread per element.
+__global__ void k_pauli_basis(int nq, double* __restrict__ out) {
+  const int d = 1 << nq;
+  const size_t total = (size_t)d * d * d * d;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % d);
+    const int r = (int)((e / d) % d);
+    const int k = (int)(e / ((size_t)d * d));
+    int xm = 0, zm = 0, ny = 0;
+    for (int b = 0; b < nq; ++b) {
+      const int dig = (k >> (2 * b)) & 3;
+      if (dig == 1 || dig == 2) xm |= 1 << b;
+      if (dig == 2 || dig == 3) zm |= 1 << b;
+      if (dig == 2) ++ny;
+    }
+    double re = 0.0, im = 0.0;
+    if (c == (r ^ xm)) {
+      const double sg = (__popc(r & zm) & 1) ? -1.0 : 1.0;
+      switch (ny & 3) {
+        case 0: re = sg; break;
+        case 1: im = -sg; break;
+        case 2: re = -sg; break;
+        default: im = sg; break;
+      }
+    }
+    out[2 * e] = re;
+    out[2 * e + 1] = im;
+  }
+}
+
+// ---- a2: measurements.py:88-93 --------------------------------------------------------------
+// out[s][k][j] = prod_q povm1[s_q][k_q][j_q], digits most-significant first, multiplied left to
+// right exactly as repeated np.kron does ((a*b)*c...).
+__global__ void k_povm_kron(int nq, const double* __restrict__ p1, int S1, int K1, double* __restrict__ out) {
+  size_t S = 1, K = 1, D = 1;
+  for (int q = 0; q < nq; ++q) {
+    S *= S1;
+    K *= K1;
+    D *= 4;
+  }
+  const size_t total = S * K * D;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    size_t j = e % D, k = (e / D) % K, s = e / (D * K);
+    // peel digits from the most significant qubit
+    size_t sdiv = S / S1, kdiv = K / K1, jdiv = D / 4;
+    double v = 0.0;
+    for (int q = 0; q < nq; ++q) {
+      const int sq = (int)(s / sdiv), kq = (int)(k / kdiv), jq = (int)(j / jdiv);
+      s %= sdiv;
+      k %= kdiv;
+      j %= jdiv;
+      const double f = p1[((size_t)sq * K1 + kq) * 4 + jq];
+      v = (q == 0) ? f : v * f;
+      if (q + 1 < nq) {
+        sdiv /= S1;
+        kdiv /= K1;
+        jdiv /= 4;
+      }
+    }
+    out[e] = v;
+  }
+}
+
+// ---- state.py:194-197: A' = A * Ns[s] / sum(Ns), plus its transpose ---------------------------
+__global__ void k_weight_povm(const double* __restrict__ A, const double* __restrict__ Ns, int S, int K, int D,
+                              double* __restrict__ Aw, double* __restrict__ AwT) {
+  double tot = 0.0;
+  for (int s = 0; s < S; ++s) tot += Ns[s];
+  const size_t M = (size_t)S * K;
+  const size_t total = M * D;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = e / D, k = e % D;
+    const double v = A[e] * Ns[m / K] / tot;
+    Aw[e] = v;
+    AwT[k * M + m] = v;
+  }
+}
+
+__global__ void k_transpose(const double* __restrict__ in, int R, int C, double* __restrict__ out) {
+  const size_t total = (size_t)R * C;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = e / C, c = e % C;
+    out[c * R + r] = in[e];
+  }
+}
+
+// ---- generic tiled GEMM  C[MxN] = op(A) op(B), real (CPLX = 0) or complex (CPLX = 1) ---------
+// Row-major operands with explicit strides; TA / TB = plain transposes (never conjugated:
+// routines.py:71 uses A.T).  16x16 output tile per 256-thread block, K staged through LDS.
+template <int CPLX>
+__global__ void __launch_bounds__(256) k_gemm(int M, int N, int K, const double* __restrict__ A, int lda, int ta,
+                                              const double* __restrict__ B, int ldb, int tb, double* __restrict__ C,
+                                              int ldc) {
+  constexpr int TS = 16;
+  constexpr int W = CPLX ? 2 : 1;
+  __shared__ double sa[TS][TS + 1][W];
+  __shared__ double sb[TS][TS + 1][W];
+  const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
+  const int row = blockIdx.y * TS + ty, col = blockIdx.x * TS + tx;
+  double accr = 0.0, acci = 0.0;
+  for (int k0 = 0; k0 < K; k0 += TS) {
+    {
+      const int ar = blockIdx.y * TS + ty, ak = k0 + tx;  // sa[ty][tx] = opA[ar][ak]
+      double vr = 0.0, vi = 0.0;
+      if (ar < M && ak < K) {
+        const size_t idx = ta ? ((size_t)ak * lda + ar) : ((size_t)ar * lda + ak);
+        vr = A[idx * W];
+        if (CPLX) vi = A[idx * W + 1];
+      }
+      sa[ty][tx][0] = vr;
+      if (CPLX) sa[ty][tx][W - 1] = vi;
+      const int bk = k0 + ty, bc = blockIdx.x * TS + tx;  // sb[ty][tx] = opB[bk][bc]
+      vr = 0.0;
+      vi = 0.0;
+      if (bk < K && bc < N) {
+        const size_t idx = tb ? ((size_t)bc * ldb + bk) : ((size_t)bk * ldb + bc);
+        vr = B[idx * W];
+        if (CPLX) vi = B[idx * W + 1];
+      }
+      sb[ty][tx][0] = vr;
+      if (CPLX) sb[ty][tx][W - 1] = vi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TS; ++kk) {
+      const double ar_ = sa[ty][kk][0], br_ = sb[kk][tx][0];
+      if (CPLX) {
+        const double ai_ = sa[ty][kk][W - 1], bi_ = sb[kk][tx][W - 1];
+        accr += ar_ * br_ - ai_ * bi_;
+        acci += ar_ * bi_ + ai_ * br_;
+      } else {
+        accr += ar_ * br_;
+      }
+    }
+    __syncthreads();
+  }
+  if (row < M && col < N) {
+    const size_t idx = (size_t)row * ldc + col;
+    C[idx * W] = accr;
+    if (CPLX) C[idx * W + 1] = acci;
+  }
+}
+
+// ---- in-place inverse by Gauss-Jordan with partial (row) pivoting ---------------------------
+// One 1024-thread workgroup; `aug` is the n x 2n augmented matrix [G | I] in global memory
+// (row-major, complex interleaved when CPLX).  On exit the right half holds inv(G).
+// info = 0 ok, k+1 if no usable pivot in column k.  (scipy.linalg.inv = LAPACK getrf/getri with
+// the same pivoting rule; routines.py:71.)
+template <int CPLX>
+__global__ void __launch_bounds__(1024) k_gauss_jordan(int n, double* __restrict__ aug, int* __restrict__ info) {
+  constexpr int W = CPLX ? 2 : 1;
+  __shared__ double s_val[1024];
+  __shared__ int s_idx[1024];
+  __shared__ double s_piv[2];
+  __shared__ int s_prow;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n2 = 2 * n;
+  for (int e = tid; e < n * n; e += nt) {  // right half = identity
+    const int r = e / n, c = e % n;
+    aug[((size_t)r * n2 + n + c) * W] = (r == c) ? 1.0 : 0.0;
+    if (CPLX) aug[((size_t)r * n2 + n + c) * W + 1] = 0.0;
+  }
+  if (tid == 0) *info = 0;
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    // pivot: max |a_ik| over i >= k  (LAPACK izamax uses |re| + |im| for complex)
+    double best = -1.0;
+    int bi = k;
+    for (int i = k + tid; i < n; i += nt) {
+      const double* p = aug + ((size_t)i * n2 + k) * W;
+      const double v = CPLX ? fabs(p[0]) + fabs(p[W - 1]) : fabs(p[0]);
+      if (v > best) {
+        best = v;
+        bi = i;
+      }
+    }
+    s_val[tid] = best;
+    s_idx[tid] = bi;
+    __syncthreads();
+    for (int s = nt / 2; s > 0; s >>= 1) {
+      if (tid < s) {
+        const double o = s_val[tid + s];
+        const int oi = s_idx[tid + s];
+        if (o > s_val[tid] || (o == s_val[tid] && oi < s_idx[tid])) {
+          s_val[tid] = o;
+          s_idx[tid] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      s_prow = s_idx[0];
+      if (!(s_val[0] > 0.0) && *info == 0) *info = k + 1;
+    }
+    __syncthreads();
+    const int pr = s_prow;
+    if (pr != k) {
+      for (int c = tid; c < n2 * W; c += nt) {
+        const double t = aug[(size_t)k * n2 * W + c];
+        aug[(size_t)k * n2 * W + c] = aug[(size_t)pr * n2 * W + c];
+        aug[(size_t)pr * n2 * W + c] = t;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_piv[0] = aug[((size_t)k * n2 + k) * W];
+      if (CPLX) s_piv[1] = aug[((size_t)k * n2 + k) * W + 1];
+    }
+    __syncthreads();
+    {  // scale the pivot row by 1 / pivot
+      const double pr_ = s_piv[0], pi_ = CPLX ? s_piv[1] : 0.0;
+      const double den = pr_ * pr_ + pi_ * pi_;
+      for (int c = tid; c < n2; c += nt) {
+        double* p = aug + ((size_t)k * n2 + c) * W;
+        if (CPLX) {
+          const double xr = p[0], xi = p[W - 1];
+          p[0] = (xr * pr_ + xi * pi_) / den;
+          p[W - 1] = (xi * pr_ - xr * pi_) / den;
+        } else {
+          p[0] = p[0] / pr_;
+        }
+      }
+    }
+    __syncthreads();
+    // eliminate column k from every other row; columns < k of the left half are already e_j
+    const int c0 = k, ncols = n2 - k;
+    const size_t work = (size_t)n * ncols;
+    for (size_t e = tid; e < work; e += nt) {
+      const int i = (int)(e / ncols), c = c0 + (int)(e % ncols);
+      if (i == k || c == k) continue;
+      const double* fk = aug + ((size_t)i * n2 + k) * W;
+      const double* rk = aug + ((size_t)k * n2 + c) * W;
+      double* p = aug + ((size_t)i * n2 + c) * W;
+      if (CPLX) {
+        const double fr = fk[0], fi = fk[W - 1], rr = rk[0], ri = rk[W - 1];
+        p[0] -= fr * rr - fi * ri;
+        p[W - 1] -= fr * ri + fi * rr;
+      } else {
+        p[0] -= fk[0] * rk[0];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {  // now clear column k itself
+      if (i == k) continue;
+      aug[((size_t)i * n2 + k) * W] = 0.0;
+      if (CPLX) aug[((size_t)i * n2 + k) * W + 1] = 0.0;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- a4: state.py:109-110  p[b][m] = clip(d * sum_k A[m][k] bloch[b][k], 0, 1) ---------------
+// 256 rows m per block, TB trials per block pass; the Bloch tile is staged in LDS and each A
+// element (read once, coalesced over m from the [D][M] layout) feeds TB accumulators.
+template <int TB>
+__global__ void __launch_bounds__(256) k_born(const double* __restrict__ AT, int M, int D, int dscale,
+                                              const double* __restrict__ bloch, int B, double* __restrict__ p) {
+  extern __shared__ double sbl[];  // [TB][D]
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  for (int b0 = blockIdx.y * TB; b0 < B; b0 += gridDim.y * TB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < TB * D; e += 256) {
+      const int t = e / D, k = e % D;
+      sbl[e] = (b0 + t < B) ? bloch[(size_t)(b0 + t) * D + k] : 0.0;
+    }
+    __syncthreads();
+    if (m < M) {
+      double acc[TB];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) acc[t] = 0.0;
+      for (int k = 0; k < D; ++k) {
+        const double a = AT[(size_t)k * M + m];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) acc[t] += a * sbl[t * D + k];
+      }
+#pragma unroll
+      for (int t = 0; t < TB; ++t)
+        if (b0 + t < B) {
+          double v = acc[t] * dscale;
+          v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+          p[(size_t)(b0 + t) * M + m] = v;
+        }
+    }
+  }
+}
+
+// ---- a3 (any n): qobj.py:126-135 / :109-118, one thread per output element --------------------
+__global__ void k_bloch_from_mat(int nq, const double* __restrict__ mat, int B, double* __restrict__ bloch) {
+  const int d = 1 << nq;
+  const size_t D = (size_t)d * d;
+  const size_t total = (size_t)B * D;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e % D);
+    const double* m = mat + (e / D) * D * 2;
+    int xm = 0, zm = 0, ny = 0;
+    for (int b = 0; b < nq; ++b) {
+      const int dig = (k >> (2 * b)) & 3;
+      if (dig == 1 || dig == 2) xm |= 1 << b;
+      if (dig == 2 || dig == 3) zm |= 1 << b;
+      if (dig == 2) ++ny;
+    }
+    double sr = 0.0, si = 0.0;
+    for (int r = 0; r < d; ++r) {
+      const double* el = m + ((size_t)r * d + (r ^ xm)) * 2;
+      const double sg = (__popc(r & zm) & 1) ? -1.0 : 1.0;
+      sr += sg * el[0];
+      si -= sg * el[1];
+    }
+    double v;
+    switch (ny & 3) {
+      case 0: v = sr; break;
+      case 1: v = si; break;
+      case 2: v = -sr; break;
+      default: v = -si; break;
+    }
+    bloch[e] = v / d;
+  }
+}
+
+__global__ void k_mat_from_bloch(int nq, const double* __restrict__ bloch, int B, double* __restrict__ mat) {
+  const int d = 1 << nq;
+  const size_t D = (size_t)d * d;
+  const size_t total = (size_t)B * D;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int el = (int)(e % D);
+    const int i = el / d, j = el % d;
+    const double* v = bloch + (e / D) * D;
+    const int x = i ^ j;
+    double sr = 0.0, si = 0.0;
+    for (int z = 0; z < d; ++z) {
+      int k = 0;
+      for (int b = 0; b < nq; ++b) {
+        const int xb = (x >> b) & 1, zb = (z >> b) & 1;
+        const int dig = xb ? (zb ? 2 : 1) : (zb ? 3 : 0);
+        k |= dig << (2 * b);
+      }
+      const double sg = (__popc(i & z) & 1) ? -1.0 : 1.0;
+      const double val = sg * v[k];
+      switch (__popc(x & z) & 3) {
+        case 0: sr += val; break;
+        case 1: si -= val; break;
+        case 2: sr -= val; break;
+        default: si += val; break;
+      }
+    }
+    mat[2 * e] = sr;
+    mat[2 * e + 1] = si;
+  }
+}
+
+// ---- a16: geometry.py:16-20, one wavefront per trial -----------------------------------------
+__global__ void __launch_bounds__(64) k_hs_dist(int d, const double* __restrict__ rho, const double* __restrict__ centre,
+                                                int B, double* __restrict__ dist) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const double* r = rho + (size_t)b * d * d * 2;
+  double sr = 0.0, si = 0.0;
+  for (int e = threadIdx.x; e < d * d; e += 64) {
+    const int i = e / d, j = e % d;
+    const int et = j * d + i;
+    const double ar = r[2 * e] - centre[2 * e], ai = r[2 * e + 1] - centre[2 * e + 1];
+    const double br = r[2 * et] - centre[2 * et], bi = r[2 * et + 1] - centre[2 * et + 1];
+    sr += ar * br - ai * bi;  // (Delta Delta)_ii summed = sum_ij Delta_ij Delta_ji
+    si += ar * bi + ai * br;
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    sr += __shfl_xor(sr, m, 64);
+    si += __shfl_xor(si, m, 64);
+  }
+  if (threadIdx.x == 0) {
+    const double v = sqrt(hypot(sr, si)) / sqrt(2.0);
+    dist[b] = v < 1e-15 ? 0.0 : v;
+  }
+}
+
+}  // namespace qt

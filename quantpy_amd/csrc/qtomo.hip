@@ -1,0 +1,568 @@
+// libqtomo.so -- C ABI (include/qtomo.h) over the HIP kernels in qt_small.h / qt_ops.h /
+// qt_process.h.  gfx950 only.  There is no CPU implementation behind these entry points.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/qtomo.h"
+#include "qt_ops.h"
+#include "qt_process.h"
+#include "qt_small.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(QT_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+}  // namespace
+
+struct qt_handle {
+  int device = 0, nq = 0, d = 0, D = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // POVM cache
+  bool povm_set = false;
+  int S = 0, K = 0, M = 0;
+  DevBuf A, AT, Aw, AwT, Pinv, PinvT, Ns, aug, info;
+  // staging for host-pointer calls
+  DevBuf in0, in1, out0, out1, out2, out3, out4;
+  // process tomography
+  qt::ProcessState proc;
+  bool proc_set = false;
+
+  qt::PovmView view() const { return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M}; }
+};
+
+namespace {
+
+int check_handle(qt_handle_t* h) {
+  if (!h) return fail(QT_ERR_ARG, "null handle");
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) return fail(QT_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
+  return 0;
+}
+
+inline int grid_for(size_t total, int block = 256, int cap = 8192) {
+  size_t g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > (size_t)cap) g = cap;
+  return (int)g;
+}
+
+// Resolve an input array: device pointer as-is, or staged copy of a host array.
+template <class T>
+int stage_in(qt_handle_t* h, DevBuf& buf, const T* src, size_t count, int flags, const T** out) {
+  if (flags & QT_DEVICE_PTR) {
+    *out = src;
+    return 0;
+  }
+  HIPCHK(buf.ensure(count * sizeof(T)));
+  HIPCHK(hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  *out = buf.as<T>();
+  return 0;
+}
+template <class T>
+int stage_out(qt_handle_t*, DevBuf& buf, T* dst, size_t count, int flags, T** out) {
+  if (!dst) {
+    *out = nullptr;
+    return 0;
+  }
+  if (flags & QT_DEVICE_PTR) {
+    *out = dst;
+    return 0;
+  }
+  HIPCHK(buf.ensure(count * sizeof(T)));
+  *out = buf.as<T>();
+  return 0;
+}
+template <class T>
+int fetch_out(qt_handle_t* h, const T* dev, T* dst, size_t count, int flags) {
+  if (!dst || (flags & QT_DEVICE_PTR)) return 0;
+  HIPCHK(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  return 0;
+}
+int finish(qt_handle_t* h, int flags) {
+  HIPCHK(hipGetLastError());
+  if (!(flags & QT_DEVICE_PTR)) HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int count_bad(const int32_t* status, int B, int flags) {
+  if (!status || (flags & QT_DEVICE_PTR)) return 0;
+  int bad = 0;
+  for (int b = 0; b < B; ++b) bad += status[b] != 0;
+  return bad;
+}
+
+template <int NQ>
+size_t small_lds_bytes(int M) {
+  return (size_t)qt::Small<NQ>::TPW * qt::Small<NQ>::lds_doubles(M) * sizeof(double);
+}
+
+#define QT_SMALL_DISPATCH(nq, CALL)                                   \
+  switch (nq) {                                                       \
+    case 1: { constexpr int NQ = 1; CALL; } break;                    \
+    case 2: { constexpr int NQ = 2; CALL; } break;                    \
+    case 3: { constexpr int NQ = 3; CALL; } break;                    \
+    default: return fail(QT_ERR_UNSUPPORTED, "estimators support n_qubits 1..3 in this release (got %d)", nq); \
+  }
+
+int need_povm(qt_handle_t* h) {
+  if (!h->povm_set) return fail(QT_ERR_STATE, "qt_set_povm has not been called on this handle");
+  return 0;
+}
+
+int check_lds(size_t bytes) {
+  if (bytes > 64 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the LDS-resident kernels (%zu bytes of LDS)", bytes);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_version(void) { return 100; }
+
+const char* qt_last_error(void) { return g_err.c_str(); }
+
+int qt_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(QT_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+qt_handle_t* qt_create(int device, int n_qubits) {
+  if (n_qubits < 1 || n_qubits > 5) {
+    fail(QT_ERR_ARG, "n_qubits must be in 1..5 (got %d)", n_qubits);
+    return nullptr;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    fail(QT_ERR_HIP, "no usable HIP device (%s); this library has no CPU path", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device < 0 || device >= n) {
+    fail(QT_ERR_ARG, "device %d out of range (have %d)", device, n);
+    return nullptr;
+  }
+  if ((e = hipSetDevice(device)) != hipSuccess) {
+    fail(QT_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  qt_handle_t* h = new qt_handle();
+  h->device = device;
+  h->nq = n_qubits;
+  h->d = 1 << n_qubits;
+  h->D = h->d * h->d;
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+    fail(QT_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e));
+    delete h;
+    return nullptr;
+  }
+  h->own_stream = true;
+  return h;
+}
+
+void qt_destroy(qt_handle_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->in0, &h->in1,
+                    &h->out0, &h->out1, &h->out2, &h->out3, &h->out4})
+    b->release();
+  h->proc.release();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int qt_sync(qt_handle_t* h) {
+  if (int r = check_handle(h)) return r;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int qt_set_stream(qt_handle_t* h, void* hip_stream) {
+  if (int r = check_handle(h)) return r;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->own_stream && h->stream) HIPCHK(hipStreamDestroy(h->stream));
+  if (hip_stream) {
+    h->stream = static_cast<hipStream_t>(hip_stream);
+    h->own_stream = false;
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  return 0;
+}
+
+int qt_timer_begin(qt_handle_t* h) {
+  if (int r = check_handle(h)) return r;
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  return 0;
+}
+
+int qt_timer_end(qt_handle_t* h, double* elapsed_ms) {
+  if (int r = check_handle(h)) return r;
+  if (!elapsed_ms) return fail(QT_ERR_ARG, "null elapsed_ms");
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *elapsed_ms = ms;
+  return 0;
+}
+
+int qt_pauli_basis(qt_handle_t* h, double* out, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (!out) return fail(QT_ERR_ARG, "null out");
+  const size_t n = (size_t)h->D * h->D * 2;
+  double* dout;
+  if (int r = stage_out(h, h->out0, out, n, flags, &dout)) return r;
+  hipLaunchKernelGGL(qt::k_pauli_basis, dim3(grid_for(n / 2)), dim3(256), 0, h->stream, h->nq, dout);
+  if (int r = fetch_out(h, dout, out, n, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_povm_kron(qt_handle_t* h, const double* povm1, int S1, int K1, double* out, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (!povm1 || !out || S1 < 1 || K1 < 1) return fail(QT_ERR_ARG, "bad povm_kron arguments");
+  size_t S = 1, K = 1;
+  for (int q = 0; q < h->nq; ++q) {
+    S *= S1;
+    K *= K1;
+  }
+  const size_t n = S * K * h->D;
+  const double* din;
+  double* dout;
+  if (int r = stage_in(h, h->in0, povm1, (size_t)S1 * K1 * 4, flags, &din)) return r;
+  if (int r = stage_out(h, h->out0, out, n, flags, &dout)) return r;
+  hipLaunchKernelGGL(qt::k_povm_kron, dim3(grid_for(n)), dim3(256), 0, h->stream, h->nq, din, S1, K1, dout);
+  if (int r = fetch_out(h, dout, out, n, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (!A || !Ns || S < 1 || K < 1) return fail(QT_ERR_ARG, "bad set_povm arguments");
+  const int D = h->D;
+  const size_t M = (size_t)S * K;
+  if (M < (size_t)D) return fail(QT_ERR_SINGULAR, "POVM has %zu rows < D = %d: not informationally complete", M, D);
+  h->povm_set = false;
+  h->proc_set = false;
+  const size_t bytes = M * D * sizeof(double);
+  HIPCHK(h->A.ensure(bytes));
+  HIPCHK(h->AT.ensure(bytes));
+  HIPCHK(h->Aw.ensure(bytes));
+  HIPCHK(h->AwT.ensure(bytes));
+  HIPCHK(h->Pinv.ensure(bytes));
+  HIPCHK(h->PinvT.ensure(bytes));
+  HIPCHK(h->Ns.ensure(S * sizeof(double)));
+  HIPCHK(h->aug.ensure((size_t)D * 2 * D * sizeof(double)));
+  HIPCHK(h->info.ensure(sizeof(int)));
+  const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(hipMemcpyAsync(h->A.p, A, bytes, kind, h->stream));
+  HIPCHK(hipMemcpyAsync(h->Ns.p, Ns, S * sizeof(double), kind, h->stream));
+  double *dA = h->A.as<double>(), *dAT = h->AT.as<double>(), *dAw = h->Aw.as<double>(), *dAwT = h->AwT.as<double>();
+  double *dP = h->Pinv.as<double>(), *dPT = h->PinvT.as<double>(), *aug = h->aug.as<double>();
+  hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dA, (int)M, D, dAT);
+  hipLaunchKernelGGL(qt::k_weight_povm, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dA, h->Ns.as<double>(), S, K, D,
+                     dAw, dAwT);
+  // Gram = A'^T A' into the left half of [G | I]
+  dim3 gg((D + 15) / 16, (D + 15) / 16);
+  hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(256), 0, h->stream, D, D, (int)M, dAw, D, 1, dAw, D, 0, aug, 2 * D);
+  hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, D, aug, h->info.as<int>());
+  // left inverse = inv(G) A'^T   (D x M)
+  dim3 gp(((int)M + 15) / 16, (D + 15) / 16);
+  hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(256), 0, h->stream, D, (int)M, D, aug + D, 2 * D, 0, dAwT, (int)M, 0, dP,
+                     (int)M);
+  hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dP, D, (int)M, dPT);
+  int info = 0;
+  HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (info != 0) return fail(QT_ERR_SINGULAR, "A^T A is singular (no pivot in column %d): POVM not informationally complete", info - 1);
+  h->S = S;
+  h->K = K;
+  h->M = (int)M;
+  h->povm_set = true;
+  return 0;
+}
+
+int qt_get_left_inverse(qt_handle_t* h, double* out, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (int r = need_povm(h)) return r;
+  if (!out) return fail(QT_ERR_ARG, "null out");
+  const size_t bytes = (size_t)h->D * h->M * sizeof(double);
+  HIPCHK(hipMemcpyAsync(out, h->Pinv.p, bytes, (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                        h->stream));
+  return finish(h, flags);
+}
+
+int qt_born_probs(qt_handle_t* h, const double* bloch, int B, double* p, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (int r = need_povm(h)) return r;
+  if (B < 0 || (B > 0 && (!bloch || !p))) return fail(QT_ERR_ARG, "bad born_probs arguments");
+  if (B == 0) return 0;
+  const double* din;
+  double* dout;
+  if (int r = stage_in(h, h->in0, bloch, (size_t)B * h->D, flags, &din)) return r;
+  if (int r = stage_out(h, h->out0, p, (size_t)B * h->M, flags, &dout)) return r;
+  const int gx = (h->M + 255) / 256;
+  if (h->D <= 256) {
+    constexpr int TB = 8;
+    int gy = (B + TB - 1) / TB;
+    if (gy > 2048) gy = 2048;
+    hipLaunchKernelGGL(qt::k_born<TB>, dim3(gx, gy), dim3(256), TB * h->D * sizeof(double), h->stream, h->AT.as<double>(),
+                       h->M, h->D, h->d, din, B, dout);
+  } else {
+    constexpr int TB = 4;
+    int gy = (B + TB - 1) / TB;
+    if (gy > 2048) gy = 2048;
+    hipLaunchKernelGGL(qt::k_born<TB>, dim3(gx, gy), dim3(256), TB * h->D * sizeof(double), h->stream, h->AT.as<double>(),
+                       h->M, h->D, h->d, din, B, dout);
+  }
+  if (int r = fetch_out(h, dout, p, (size_t)B * h->M, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_bloch_from_mat(qt_handle_t* h, const double* mat, int B, double* bloch, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (B < 0 || (B > 0 && (!mat || !bloch))) return fail(QT_ERR_ARG, "bad bloch_from_mat arguments");
+  if (B == 0) return 0;
+  const double* din;
+  double* dout;
+  const size_t n = (size_t)B * h->D;
+  if (int r = stage_in(h, h->in0, mat, n * 2, flags, &din)) return r;
+  if (int r = stage_out(h, h->out0, bloch, n, flags, &dout)) return r;
+  hipLaunchKernelGGL(qt::k_bloch_from_mat, dim3(grid_for(n)), dim3(256), 0, h->stream, h->nq, din, B, dout);
+  if (int r = fetch_out(h, dout, bloch, n, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_mat_from_bloch(qt_handle_t* h, const double* bloch, int B, double* mat, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (B < 0 || (B > 0 && (!mat || !bloch))) return fail(QT_ERR_ARG, "bad mat_from_bloch arguments");
+  if (B == 0) return 0;
+  const double* din;
+  double* dout;
+  const size_t n = (size_t)B * h->D;
+  if (int r = stage_in(h, h->in0, bloch, n, flags, &din)) return r;
+  if (int r = stage_out(h, h->out0, mat, n * 2, flags, &dout)) return r;
+  hipLaunchKernelGGL(qt::k_mat_from_bloch, dim3(grid_for(n)), dim3(256), 0, h->stream, h->nq, din, B, dout);
+  if (int r = fetch_out(h, dout, mat, n * 2, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, double* rho, double* bloch_out,
+                 int32_t* status, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (int r = need_povm(h)) return r;
+  if (B < 0 || (B > 0 && (!counts || !rho))) return fail(QT_ERR_ARG, "bad lin_batch arguments");
+  if (B == 0) return 0;
+  const int64_t* dc;
+  double *drho, *dbl;
+  int32_t* dst;
+  const size_t nel = (size_t)B * h->D;
+  if (int r = stage_in(h, h->in0, counts, (size_t)B * h->M, flags, &dc)) return r;
+  if (int r = stage_out(h, h->out0, rho, nel * 2, flags, &drho)) return r;
+  if (int r = stage_out(h, h->out1, bloch_out, nel, flags, &dbl)) return r;
+  if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
+  QT_SMALL_DISPATCH(h->nq, {
+    const size_t lds = small_lds_bytes<NQ>(h->M);
+    if (int r = check_lds(lds)) return r;
+    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
+    hipLaunchKernelGGL(qt::k_lin_batch<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dc, B, physical, drho, dbl,
+                       dst);
+  });
+  if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;
+  if (int r = fetch_out(h, dbl, bloch_out, nel, flags)) return r;
+  if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
+  if (int r = finish(h, flags)) return r;
+  return count_bad(status, B, flags);
+}
+
+int qt_chol_param(qt_handle_t* h, const double* rho, int B, double* x, int32_t* status, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (B < 0 || (B > 0 && (!rho || !x))) return fail(QT_ERR_ARG, "bad chol_param arguments");
+  if (B == 0) return 0;
+  const double* din;
+  double* dx;
+  int32_t* dst;
+  const size_t nel = (size_t)B * h->D;
+  if (int r = stage_in(h, h->in0, rho, nel * 2, flags, &din)) return r;
+  if (int r = stage_out(h, h->out0, x, nel, flags, &dx)) return r;
+  if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
+  qt::PovmView pv{nullptr, nullptr, nullptr, 0};
+  QT_SMALL_DISPATCH(h->nq, {
+    const size_t lds = small_lds_bytes<NQ>(0);
+    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
+    hipLaunchKernelGGL(qt::k_chol_param<NQ>, dim3(grid), dim3(64), lds, h->stream, pv, din, B, dx, dst);
+  });
+  if (int r = fetch_out(h, dx, x, nel, flags)) return r;
+  if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
+  if (int r = finish(h, flags)) return r;
+  return count_bad(status, B, flags);
+}
+
+int qt_chol_unparam(qt_handle_t* h, const double* x, int B, double* LLh, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (B < 0 || (B > 0 && (!x || !LLh))) return fail(QT_ERR_ARG, "bad chol_unparam arguments");
+  if (B == 0) return 0;
+  const double* din;
+  double* dout;
+  const size_t nel = (size_t)B * h->D;
+  if (int r = stage_in(h, h->in0, x, nel, flags, &din)) return r;
+  if (int r = stage_out(h, h->out0, LLh, nel * 2, flags, &dout)) return r;
+  qt::PovmView pv{nullptr, nullptr, nullptr, 0};
+  QT_SMALL_DISPATCH(h->nq, {
+    const size_t lds = small_lds_bytes<NQ>(0);
+    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
+    hipLaunchKernelGGL(qt::k_chol_unparam<NQ>, dim3(grid), dim3(64), lds, h->stream, pv, din, B, dout);
+  });
+  if (int r = fetch_out(h, dout, LLh, nel * 2, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_nll_batch(qt_handle_t* h, const double* x, const int64_t* counts, int B, double* f, double* grad, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (int r = need_povm(h)) return r;
+  if (B < 0 || (B > 0 && (!x || !counts || !f))) return fail(QT_ERR_ARG, "bad nll_batch arguments");
+  if (B == 0) return 0;
+  const double* dx;
+  const int64_t* dc;
+  double *df, *dg;
+  const size_t nel = (size_t)B * h->D;
+  if (int r = stage_in(h, h->in0, x, nel, flags, &dx)) return r;
+  if (int r = stage_in(h, h->in1, counts, (size_t)B * h->M, flags, &dc)) return r;
+  if (int r = stage_out(h, h->out0, f, (size_t)B, flags, &df)) return r;
+  if (int r = stage_out(h, h->out1, grad, nel, flags, &dg)) return r;
+  QT_SMALL_DISPATCH(h->nq, {
+    const size_t lds = small_lds_bytes<NQ>(h->M);
+    if (int r = check_lds(lds)) return r;
+    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
+    hipLaunchKernelGGL(qt::k_nll_batch<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dx, dc, B, df, dg);
+  });
+  if (int r = fetch_out(h, df, f, (size_t)B, flags)) return r;
+  if (int r = fetch_out(h, dg, grad, nel, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol, double* rho,
+                 int32_t* nit, int32_t* nfev, double* fun, int32_t* status, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (int r = need_povm(h)) return r;
+  if (B < 0 || (B > 0 && (!counts || !rho))) return fail(QT_ERR_ARG, "bad mle_batch arguments");
+  if (init != QT_INIT_LIN && init != QT_INIT_MIXED) return fail(QT_ERR_ARG, "init must be QT_INIT_LIN or QT_INIT_MIXED");
+  if (max_iter < 0) return fail(QT_ERR_ARG, "max_iter < 0");
+  if (B == 0) return 0;
+  const int64_t* dc;
+  double *drho, *dfun;
+  int32_t *dnit, *dnfev, *dst;
+  const size_t nel = (size_t)B * h->D;
+  if (int r = stage_in(h, h->in0, counts, (size_t)B * h->M, flags, &dc)) return r;
+  if (int r = stage_out(h, h->out0, rho, nel * 2, flags, &drho)) return r;
+  if (int r = stage_out(h, h->out1, nit, (size_t)B, flags, &dnit)) return r;
+  if (int r = stage_out(h, h->out2, nfev, (size_t)B, flags, &dnfev)) return r;
+  if (int r = stage_out(h, h->out3, fun, (size_t)B, flags, &dfun)) return r;
+  if (int r = stage_out(h, h->out4, status, (size_t)B, flags, &dst)) return r;
+  QT_SMALL_DISPATCH(h->nq, {
+    const size_t lds = small_lds_bytes<NQ>(h->M);
+    if (int r = check_lds(lds)) return r;
+    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
+    hipLaunchKernelGGL(qt::k_mle_batch<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dc, B, init, max_iter, tol,
+                       drho, dnit, dnfev, dfun, dst);
+  });
+  if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;
+  if (int r = fetch_out(h, dnit, nit, (size_t)B, flags)) return r;
+  if (int r = fetch_out(h, dnfev, nfev, (size_t)B, flags)) return r;
+  if (int r = fetch_out(h, dfun, fun, (size_t)B, flags)) return r;
+  if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
+  if (int r = finish(h, flags)) return r;
+  return count_bad(status, B, flags);
+}
+
+int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, int B, double* dist, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (B < 0 || (B > 0 && (!rho || !centre || !dist))) return fail(QT_ERR_ARG, "bad hs_dist arguments");
+  if (B == 0) return 0;
+  const double *dr, *dcn;
+  double* dd;
+  if (int r = stage_in(h, h->in0, rho, (size_t)B * h->D * 2, flags, &dr)) return r;
+  if (int r = stage_in(h, h->in1, centre, (size_t)h->D * 2, flags, &dcn)) return r;
+  if (int r = stage_out(h, h->out0, dist, (size_t)B, flags, &dd)) return r;
+  hipLaunchKernelGGL(qt::k_hs_dist, dim3(B), dim3(64), 0, h->stream, h->d, dr, dcn, B, dd);
+  if (int r = fetch_out(h, dd, dist, (size_t)B, flags)) return r;
+  return finish(h, flags);
+}
+
+// ---- process tomography: see qt_process.h -----------------------------------------------------
+int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (int r = need_povm(h)) return r;
+  (void)in_states;
+  (void)flags;
+  return fail(QT_ERR_UNSUPPORTED, "process tomography kernels are not built yet");
+}
+int qt_process_get_operators(qt_handle_t* h, double*, double*, int) {
+  if (int r = check_handle(h)) return r;
+  return fail(QT_ERR_UNSUPPORTED, "process tomography kernels are not built yet");
+}
+int qt_lifp_batch(qt_handle_t* h, const int64_t*, int, int, double*, int32_t*, int32_t*, int) {
+  if (int r = check_handle(h)) return r;
+  return fail(QT_ERR_UNSUPPORTED, "process tomography kernels are not built yet");
+}
+int qt_cptp_project_batch(qt_handle_t* h, const double*, int, int, int, double, double*, int32_t*, int) {
+  if (int r = check_handle(h)) return r;
+  return fail(QT_ERR_UNSUPPORTED, "process tomography kernels are not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+"""NumPy-facing wrapper of the C ABI (include/qtomo.h): one `Engine` per (n_qubits, device).
+
+Every method is a thin marshalling layer over one `qt_*` entry point -- the arithmetic is in the
+HIP kernels.  Inputs are NumPy arrays (host-pointer calls, synchronous) or torch CUDA tensors
+(device-pointer calls, asynchronous on the engine's stream; outputs must then be passed in).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _capi
+
+_STATUS_TEXT = {
+    _capi.TRIAL_NOT_PD: "matrix is not positive definite (Cholesky)",
+    _capi.TRIAL_LINESEARCH: "line search failed (precision loss)",
+    _capi.TRIAL_MAXITER: "maximum number of iterations reached",
+    _capi.TRIAL_NAN: "NaN encountered",
+}
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libqtomo error {code}: {text}")
+        self.code = code
+
+
+def _is_dev(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_dev(x):
+        assert x.is_cuda and x.is_contiguous()
+        return ctypes.c_void_p(x.data_ptr())
+    return x.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _c128(a):
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def _i64(a):
+    a = np.asarray(a)
+    if a.dtype != np.int64:
+        if not np.issubdtype(a.dtype, np.integer):
+            if not np.all(np.equal(np.mod(a, 1), 0)):
+                raise TypeError("counts must be integers")
+        a = a.astype(np.int64)
+    return np.ascontiguousarray(a)
+
+
+class Engine:
+    """Owns a qt_handle (device buffers, stream, cached POVM operators) for `n_qubits`."""
+
+    def __init__(self, n_qubits, device=0):
+        self.lib = _capi.load()
+        self.n = int(n_qubits)
+        self.d = 2**self.n
+        self.D = 4**self.n
+        self.device = device
+        self._h = self.lib.qt_create(device, self.n)
+        if not self._h:
+            raise _capi.EngineUnavailable(_capi.last_error())
+        self._povm_key = None
+        self.S = self.K = self.M = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.qt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, code):
+        if code < 0:
+            raise EngineError(code, _capi.last_error())
+        return code
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def sync(self):
+        self._chk(self.lib.qt_sync(self._h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.qt_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def timer_begin(self):
+        self._chk(self.lib.qt_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = ctypes.c_double()
+        self._chk(self.lib.qt_timer_end(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- a1 / a2 ----------------------------------------------------------------------------
+    def pauli_basis(self):
+        out = np.empty((self.D, self.d, self.d), dtype=np.complex128)
+        self._chk(self.lib.qt_pauli_basis(self._h, _ptr(out), _capi.QT_HOST_PTR))
+        return out
+
+    def povm_kron(self, table):
+        """table (S1, K1, 4) -> (S1^n, K1^n, 4^n)"""
+        table = _f64(table)
+        if table.ndim == 2:
+            table = table[None]
+        s1, k1, four = table.shape
+        assert four == 4
+        out = np.empty((s1**self.n, k1**self.n, self.D))
+        self._chk(self.lib.qt_povm_kron(self._h, _ptr(table), s1, k1, _ptr(out), _capi.QT_HOST_PTR))
+        return out
+
+    # ---- a5 ---------------------------------------------------------------------------------
+    def set_povm(self, povm_matrix, n_meas):
+        """Cache A (S, K, D), the shot weights and the left inverse.  Re-uploading the same
+        (povm, shots) pair is skipped."""
+        a = _f64(povm_matrix)
+        if a.ndim == 2:
+            a = a[None]
+        s, k, dd = a.shape
+        if dd != self.D:
+            raise ValueError("Incorrect POVM matrix")
+        ns = _f64(np.broadcast_to(np.asarray(n_meas, dtype=np.float64), (s,)))
+        key = (a.shape, a.tobytes(), ns.tobytes())
+        if key == self._povm_key:
+            return
+        self._povm_key = None
+        self._chk(self.lib.qt_set_povm(self._h, _ptr(a), s, k, _ptr(ns), _capi.QT_HOST_PTR))
+        self._povm_key = key
+        self.S, self.K, self.M = s, k, s * k
+
+    def left_inverse(self):
+        out = np.empty((self.D, self.M))
+        self._chk(self.lib.qt_get_left_inverse(self._h, _ptr(out), _capi.QT_HOST_PTR))
+        return out
+
+    # ---- a4 / a3 ----------------------------------------------------------------------------
+    def born_probs(self, bloch, out=None):
+        if _is_dev(bloch):
+            b = bloch.shape[0]
+            self._chk(self.lib.qt_born_probs(self._h, _ptr(bloch), b, _ptr(out), _capi.QT_DEVICE_PTR))
+            return out
+        bloch = _f64(bloch)
+        single = bloch.ndim == 1
+        bl = bloch.reshape(-1, self.D)
+        p = np.empty((bl.shape[0], self.S, self.K))
+        self._chk(self.lib.qt_born_probs(self._h, _ptr(bl), bl.shape[0], _ptr(p), _capi.QT_HOST_PTR))
+        return p[0] if single else p
+
+    def bloch_from_matrix(self, mat):
+        mat = _c128(mat)
+        single = mat.ndim == 2
+        m = mat.reshape(-1, self.d, self.d)
+        out = np.empty((m.shape[0], self.D))
+        self._chk(self.lib.qt_bloch_from_mat(self._h, _ptr(m), m.shape[0], _ptr(out), _capi.QT_HOST_PTR))
+        return out[0] if single else out
+
+    def matrix_from_bloch(self, bloch):
+        bloch = _f64(bloch)
+        single = bloch.ndim == 1
+        b = bloch.reshape(-1, self.D)
+        out = np.empty((b.shape[0], self.d, self.d), dtype=np.complex128)
+        self._chk(self.lib.qt_mat_from_bloch(self._h, _ptr(b), b.shape[0], _ptr(out), _capi.QT_HOST_PTR))
+        return out[0] if single else out
+
+    # ---- a6 / a7 ----------------------------------------------------------------------------
+    def _counts(self, counts):
+        c = _i64(counts)
+        single = c.ndim == 2
+        c = c.reshape(-1, self.S, self.K) if c.size else c.reshape(0, self.S, self.K)
+        return c, single
+
+    def lin(self, counts, physical=True, return_bloch=False):
+        c, single = self._counts(counts)
+        b = c.shape[0]
+        rho = np.empty((b, self.d, self.d), dtype=np.complex128)
+        bloch = np.empty((b, self.D)) if return_bloch else None
+        status = np.zeros(b, dtype=np.int32)
+        self._chk(self.lib.qt_lin_batch(self._h, _ptr(c), b, int(bool(physical)), _ptr(rho), _ptr(bloch), _ptr(status),
+                                        _capi.QT_HOST_PTR))
+        if single:
+            return (rho[0], bloch[0]) if return_bloch else rho[0]
+        return (rho, bloch) if return_bloch else rho
+
+    def lin_dev(self, counts, rho, physical=True, bloch=None, status=None):
+        """device-pointer form: counts int64 (B, S, K), rho complex128 (B, d, d) torch CUDA tensors"""
+        self._chk(self.lib.qt_lin_batch(self._h, _ptr(counts), counts.shape[0], int(bool(physical)), _ptr(rho),
+                                        _ptr(bloch), _ptr(status), _capi.QT_DEVICE_PTR))
+
+    # ---- a8 / a9 ----------------------------------------------------------------------------
+    def chol_param(self, rho):
+        rho = _c128(rho)
+        single = rho.ndim == 2
+        r = rho.reshape(-1, self.d, self.d)
+        x = np.empty((r.shape[0], self.D))
+        status = np.zeros(r.shape[0], dtype=np.int32)
+        self._chk(self.lib.qt_chol_param(self._h, _ptr(r), r.shape[0], _ptr(x), _ptr(status), _capi.QT_HOST_PTR))
+        return (x[0], status[0]) if single else (x, status)
+
+    def chol_unparam(self, x):
+        x = _f64(x)
+        single = x.ndim == 1
+        xx = x.reshape(-1, self.D)
+        out = np.empty((xx.shape[0], self.d, self.d), dtype=np.complex128)
+        self._chk(self.lib.qt_chol_unparam(self._h, _ptr(xx), xx.shape[0], _ptr(out), _capi.QT_HOST_PTR))
+        return out[0] if single else out
+
+    def nll(self, x, counts, grad=True):
+        x = _f64(x)
+        c, single = self._counts(counts)
+        xx = x.reshape(-1, self.D)
+        b = xx.shape[0]
+        assert c.shape[0] == b
+        f = np.empty(b)
+        g = np.empty((b, self.D)) if grad else None
+        self._chk(self.lib.qt_nll_batch(self._h, _ptr(xx), _ptr(c), b, _ptr(f), _ptr(g), _capi.QT_HOST_PTR))
+        if single:
+            return (f[0], g[0]) if grad else f[0]
+        return (f, g) if grad else f
+
+    # ---- a10 --------------------------------------------------------------------------------
+    def mle(self, counts, init="lin", max_iter=100, tol=1e-3, return_info=False):
+        if init not in ("lin", "mixed"):
+            raise ValueError("Invalid value for argument `init`")
+        c, single = self._counts(counts)
+        b = c.shape[0]
+        rho = np.empty((b, self.d, self.d), dtype=np.complex128)
+        nit = np.zeros(b, dtype=np.int32)
+        nfev = np.zeros(b, dtype=np.int32)
+        fun = np.zeros(b)
+        status = np.zeros(b, dtype=np.int32)
+        self._chk(self.lib.qt_mle_batch(self._h, _ptr(c), b, _capi.QT_INIT_LIN if init == "lin" else _capi.QT_INIT_MIXED,
+                                        int(max_iter), float(tol), _ptr(rho), _ptr(nit), _ptr(nfev), _ptr(fun),
+                                        _ptr(status), _capi.QT_HOST_PTR))
+        if single:
+            rho, nit, nfev, fun, status = rho[0], nit[0], nfev[0], fun[0], status[0]
+        if return_info:
+            return rho, dict(nit=nit, nfev=nfev, fun=fun, status=status)
+        return rho
+
+    def mle_dev(self, counts, rho, init="lin", max_iter=100, tol=1e-3, nit=None, nfev=None, fun=None, status=None):
+        self._chk(self.lib.qt_mle_batch(self._h, _ptr(counts), counts.shape[0],
+                                        _capi.QT_INIT_LIN if init == "lin" else _capi.QT_INIT_MIXED, int(max_iter),
+                                        float(tol), _ptr(rho), _ptr(nit), _ptr(nfev), _ptr(fun), _ptr(status),
+                                        _capi.QT_DEVICE_PTR))
+
+    # ---- a16 --------------------------------------------------------------------------------
+    def hs_dist(self, rho, centre):
+        rho = _c128(rho)
+        centre = _c128(centre)
+        single = rho.ndim == 2
+        r = rho.reshape(-1, self.d, self.d)
+        out = np.empty(r.shape[0])
+        self._chk(self.lib.qt_hs_dist_batch(self._h, _ptr(r), _ptr(centre), r.shape[0], _ptr(out), _capi.QT_HOST_PTR))
+        return out[0] if single else out
+
+    def hs_dist_dev(self, rho, centre, out):
+        self._chk(self.lib.qt_hs_dist_batch(self._h, _ptr(rho), _ptr(centre), rho.shape[0], _ptr(out),
+                                            _capi.QT_DEVICE_PTR))
+
+
+_ENGINES = {}
+
+
+def get_engine(n_qubits, device=0):
+    """Process-wide engine cache: one handle per (n_qubits, device)."""
+    key = (int(n_qubits), int(device))
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = _ENGINES[key] = Engine(n_qubits, device)
+    return eng
+
+
+def status_text(code):
+    return _STATUS_TEXT.get(int(code), "ok")

@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: state reconstructions/s, 3-qubit MLE (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: qt_mle_batch on B = 1000 independent
+3-qubit trials per GPU ('proj-set' POVM, 1e5 shots per setting, Ginibre state of
+np.random.default_rng(1234); counts drawn on the host from np.random.seed(7) in the
+reference's call order -- SURVEY.md section 8d).  Counts are resident in HBM before the timed
+region.  N > 1 (torchrun, one rank per GPU): each rank reconstructs its own 1000 trials
+(weak scaling, no data-path collective); afterwards the 2000-resample bootstrap CI of
+configs[3] is run strong-scaled with one RCCL all-gather and reported under "bootstrap_ci".
+
+Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+  "roofline":     the dominant kernel (k_mle_batch<3>) against the HBM roofline, from HIP-event
+                  timing of back-to-back launches on the engine's stream;
+  "cpu_baseline": the CPU oracle (oracle/quantpy_oracle.py: scipy BFGS + forward differences,
+                  i.e. the reference's algorithm) timed on one host core on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # vector FP64, SURVEY.md section 8d
+
+
+def ginibre(rng, d):
+    g = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    rho = g @ g.conj().T
+    return rho / np.trace(rho)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1000, help="trials per GPU per step (configs[1]: 1000)")
+    ap.add_argument("--shots", type=int, default=100000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2000, help="trials timed on the CPU oracle")
+    ap.add_argument("--bootstrap-points", type=int, default=2000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import quantpy_amd as qp
+    from quantpy_amd.tomography.state import simulate_counts
+
+    n, d, B = 3, 8, args.batch
+    rho_true = ginibre(np.random.default_rng(1234), d)
+    state = qp.Qobj(rho_true)
+    povm = qp.generate_measurement_matrix("proj-set", n)  # (27, 8, 64), assembled on the GPU
+    S, K, D = povm.shape
+    M = S * K
+    shots = np.ones(S) * args.shots
+
+    # ---- synthetic counts: one global legacy stream, rank r owns trials [r*B, (r+1)*B) --------
+    np.random.seed(7)
+    bloch = state.bloch
+    all_counts = np.stack([simulate_counts(povm, bloch, shots) for _ in range(B * world)])
+    counts = all_counts[rank * B:(rank + 1) * B]
+
+    eng = qp.get_engine(n, device=local_rank)
+    eng.set_povm(povm, shots)
+    counts_d = torch.from_numpy(np.ascontiguousarray(counts)).cuda()
+    rho_d = torch.empty((B, d, d), dtype=torch.complex128, device="cuda")
+    nit_d = torch.zeros(B, dtype=torch.int32, device="cuda")
+    nfev_d = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st_d = torch.zeros(B, dtype=torch.int32, device="cuda")
+
+    def step():
+        eng.mle_dev(counts_d, rho_d, init="lin", max_iter=100, tol=1e-3, nit=nit_d, nfev=nfev_d, status=st_d)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.timer_begin()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = eng.timer_end() / args.steps  # HIP events on the stream the kernel runs on
+    eng.sync()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    nit = nit_d.cpu().numpy()
+    nfev = nfev_d.cpu().numpy()
+    status = st_d.cpu().numpy()
+    rho_h = rho_d.cpu().numpy()
+    assert np.all(status == 0), "non-zero trial status in the benchmark batch"
+    value = world * B * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (algorithmic bytes per reconstruction) -----
+    bytes_per_recon = 8 * M + 16 * d * d + 2 * (8 * M * D) / B  # counts in, rho out, A' and A'^T amortised
+    launch_bytes = bytes_per_recon * B
+    achieved_gbs = launch_bytes / (kernel_ms * 1e-3) / 1e9
+    # FP64 work actually executed per launch (analytic gradient): per evaluation 2*(2 M D) for the two
+    # POVM contractions + small d^3 terms; per trial one linear inversion 2 M D and a Jacobi eigensolve
+    flops_eval = 4 * M * D + 16 * D * d + 2 * 8 * d**3
+    flops_trial = 2 * M * D + 8 * D * d + 60 * 8 * d**3 + float(nfev.mean()) * flops_eval
+    fp64_tflops = flops_trial * B / (kernel_ms * 1e-3) / 1e12
+    roofline = {
+        "bound": "hbm", "kernel": "k_mle_batch<3>", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+        "bytes_per_launch": int(launch_bytes), "kernel_ms": round(kernel_ms, 5),
+        "note": "n=3 working set is LDS/register resident: the kernel is FP64-VALU/latency bound, not HBM bound "
+                "(SURVEY 8d); fp64 fraction reported beside it",
+        "fp64": {"achieved": round(fp64_tflops, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(fp64_tflops / FP64_PEAK_TFLOPS, 6)},
+    }
+
+    # ---- bootstrap CI (configs[3]): strong scaling over ranks, one all-gather -------------------
+    boot = None
+    if args.bootstrap_points > 0:
+        tmg = qp.StateTomograph(state)
+        tmg.povm_matrix = povm
+        tmg.results = all_counts[0]
+        centre = tmg.point_estimate("mle")
+        np.random.seed(4242)
+        # draw the resamples first (host RNG, untimed input generation), then time reconstruction
+        # + distances + gather + quantiles  (what BootstrapStateInterval.setup does, split for timing)
+        res = [simulate_counts(povm, centre.bloch, tmg.n_measurements) for _ in range(args.bootstrap_points)]
+        res = np.stack(res)
+        from quantpy_amd import distributed as qd
+
+        lo, hi = qd.shard_bounds(len(res))
+        shard_d = torch.from_numpy(np.ascontiguousarray(res[lo:hi])).cuda()
+        rho_b = torch.empty((hi - lo, d, d), dtype=torch.complex128, device="cuda")
+        dist_b = torch.empty(hi - lo, dtype=torch.float64, device="cuda")
+        centre_d = torch.from_numpy(np.ascontiguousarray(centre.matrix)).cuda()
+        torch.cuda.synchronize()
+        barrier()
+        tb = time.perf_counter()
+        eng.mle_dev(shard_d, rho_b)
+        eng.hs_dist_dev(rho_b, centre_d, dist_b)
+        eng.sync()
+        full = qd.allgather_concat(dist_b.cpu().numpy(), len(res))
+        q = np.interp([0.5, 0.9, 0.95], np.linspace(0, 1, len(full)), np.sort(full))
+        torch.cuda.synchronize()
+        barrier()
+        boot_ms = (time.perf_counter() - tb) * 1e3
+        if world > 1:
+            t = torch.tensor([boot_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            boot_ms = float(t.item())
+        boot = {"n_points": args.bootstrap_points, "wall_ms": round(boot_ms, 3), "scaling": "strong",
+                "quantiles_hs": [round(float(x), 8) for x in q], "conf_levels": [0.5, 0.9, 0.95],
+                "timed": "reconstruct + distances + all-gather + quantiles (resampling on the host RNG is input generation)"}
+
+    # ---- CPU baseline: the oracle on a bounded sample, one host core (rank 0, N = 1 only) -------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import quantpy_oracle as qo
+
+        try:
+            from threadpoolctl import threadpool_limits
+
+            limiter = threadpool_limits(limits=1)
+        except Exception:
+            limiter = None
+        ns = args.cpu_sample
+        tc = time.perf_counter()
+        worst = 0.0
+        for i in range(ns):
+            ref = qo.mle_estimate(counts[i % B], povm)
+            if i < 64:
+                worst = max(worst, abs(qo.infidelity(ref, rho_h[i])))
+        cpu_s = time.perf_counter() - tc
+        if limiter is not None:
+            limiter.unregister() if hasattr(limiter, "unregister") else None
+        cpu = {"value": round(ns / cpu_s, 3), "unit": "reconstructions/s", "cores": 1, "kind": "port",
+               "sample": f"{ns} reconstructions cycling over the {B} trials of this workload, oracle/quantpy_oracle.mle_estimate "
+                         f"(scipy BFGS + forward differences = the reference's algorithm), {cpu_s:.1f} s",
+               "max_infidelity_gpu_vs_cpu_first64": float(f"{worst:.3e}"),
+               "reference_itself": "25 reconstructions/s/core measured in the dev container (BASELINE.md section 2)"}
+
+    if rank == 0:
+        line = {
+            "metric": "state reconstructions/sec (3-qubit MLE)", "value": round(value, 1),
+            "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: 3-qubit random mixed state, 'proj-set' POVM (27 settings x 8 outcomes), "
+                                   "1e5 shots/setting, point_estimate('mle'), 1k-trial batch per GPU",
+                       "n_qubits": n, "batch_per_gpu": B, "shots_per_setting": args.shots, "povm": "proj-set",
+                       "parallelism": f"trials sharded over {world} GPU(s), no data-path collective"},
+            "bfgs": {"mean_nit": float(nit.mean()), "mean_nfev": float(nfev.mean()),
+                     "reference_equivalent_nfev": float(nfev.mean()) * (D + 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "bootstrap_ci": boot,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,10 @@ int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns,
 /* out[D][M]: the cached left inverse (for inspection / tests) */
 int qt_get_left_inverse(qt_handle_t* h, double* out, int flags);
 
+/* the same left inverse for an arbitrary rows x cols matrix, real (is_complex = 0) or complex
+ * (interleaved; still the PLAIN transpose, as routines.py:71 writes it): out[cols][rows] */
+int qt_left_inverse(qt_handle_t* h, const double* A, int rows, int cols, int is_complex, double* out, int flags);
+
 /* ---- a4: quantpy/tomography/state.py:109-110 (probabilities only; sampling stays on host) -- */
 /* p[B][S][K] = clip(d * sum_k A[s][k'][k] bloch[b][k], 0, 1) */
 int qt_born_probs(qt_handle_t* h, const double* bloch, int B, double* p, int flags);

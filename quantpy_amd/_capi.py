@@ -35,6 +35,7 @@ SIGNATURES = {
     "qt_povm_kron": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _c_int]),
     "qt_set_povm": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _c_int]),
     "qt_get_left_inverse": (_c_int, [_vp, _vp, _c_int]),
+    "qt_left_inverse": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int]),
     "qt_born_probs": (_c_int, [_vp, _vp, _c_int, _vp, _c_int]),
     "qt_bloch_from_mat": (_c_int, [_vp, _vp, _c_int, _vp, _c_int]),
     "qt_mat_from_bloch": (_c_int, [_vp, _vp, _c_int, _vp, _c_int]),

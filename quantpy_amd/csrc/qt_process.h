@@ -1,4 +1,12 @@
-// Process-tomography device state and kernels (reference quantpy/tomography/process.py).
+// Process-tomography kernels (reference quantpy/tomography/process.py).
+//
+//   design matrix   rows vec(rho_in (x) E_m^T), column stacking          process.py:203-208
+//   linear inversion Choi = vec2mat(A^+ f), f per-input-state frequencies  process.py:284-286
+//   CPTP projection  Dykstra alternation of the TP and CP projections      process.py:231-278
+//
+// One workgroup reconstructs one process: thread (r, c) owns element C[r][c] of the DC x DC Choi
+// matrix (DC = 4^n: 4 or 16) through the whole Dykstra loop; the TP step is a partial-trace
+// reduction in LDS, the CP step a parallel-order Jacobi eigensolver in LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -6,7 +14,368 @@
 namespace qt {
 
 struct ProcessState {
-  void release() {}
+  void* lifp = nullptr;      // [D*M][D^2] complex design matrix
+  void* pinvT = nullptr;     // [D*M][D^2] complex: transpose of its left inverse
+  void* emats = nullptr;     // [M][d][d] complex POVM elements
+  void* in_states = nullptr; // [D][d][d] complex
+  void* aug = nullptr;       // [D^2][2 D^2] complex Gauss-Jordan workspace
+  void* pinv = nullptr;      // [D^2][D*M] complex
+  size_t cap_rows = 0;
+  void release() {
+    for (void** p : {&lifp, &pinvT, &emats, &in_states, &aug, &pinv}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    cap_rows = 0;
+  }
 };
+
+// lifp[(s*M + m)][col*d^2 + row] = rho_s[a][c] * E_m[e][b],  row = a*d + b, col = c*d + e
+__global__ void k_lifp_rows(int d, int M, const double* __restrict__ in_states, const double* __restrict__ emats,
+                            double* __restrict__ lifp) {
+  const int D = d * d;
+  const size_t ncol = (size_t)D * D;
+  const size_t total = (size_t)D * M * ncol;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t v = t % ncol, rr = t / ncol;
+    const int s = (int)(rr / M), m = (int)(rr % M);
+    const int row = (int)(v % D), col = (int)(v / D);
+    const int a = row / d, b = row % d, c = col / d, e = col % d;
+    const double* rho = in_states + ((size_t)s * D + a * d + c) * 2;
+    const double* em = emats + ((size_t)m * D + e * d + b) * 2;
+    lifp[2 * t] = rho[0] * em[0] - rho[1] * em[1];
+    lifp[2 * t + 1] = rho[0] * em[1] + rho[1] * em[0];
+  }
+}
+
+__global__ void k_transpose_c(const double* __restrict__ in, int R, int C, double* __restrict__ out) {
+  const size_t total = (size_t)R * C;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = e / C, c = e % C;
+    out[2 * (c * R + r)] = in[2 * e];
+    out[2 * (c * R + r) + 1] = in[2 * e + 1];
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  constexpr int NW = (NT + 63) / 64;
+  if (NW == 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) s += scratch[w];
+  return s;
+}
+
+template <int DC>
+struct ProcWG {
+  static constexpr int NE = DC * DC;               // matrix elements = active threads
+  static constexpr int NT = NE < 64 ? 64 : NE;     // workgroup size
+  static constexpr int DQ = (DC == 4) ? 2 : (DC == 16 ? 4 : 8);  // d = sqrt(DC)
+
+  struct Sh {
+    double are[NE], aim[NE];   // work matrix
+    double tre[NE], tim[NE];   // column-rotated matrix
+    double vre[2][NE], vim[2][NE];  // eigenvectors, double buffered
+    double rc[DC], ore[DC], oim[DC];
+    double red[16];
+    double rre[DQ * DQ], rim[DQ * DQ];  // reduced (input-space) matrix of the TP step
+  };
+
+  __device__ __forceinline__ static int partner(int i, int r) {
+    if (i == DC - 1) return r;
+    if (i == r) return DC - 1;
+    int p = (2 * r - i) % (DC - 1);
+    if (p < 0) p += DC - 1;
+    return p;
+  }
+
+  // CP projection (process.py:270-277): eigh on the lower triangle, clip at eps, rebuild.
+  // (re, im) = this thread's element (i, j); returns the projected element.
+  __device__ static void cp_project(Sh& sh, bool act, int i, int j, double& re, double& im, double eps) {
+    const int e = i * DC + j;
+    // Hermitian completion from the lower triangle, like LAPACK's zheevd with uplo = 'L'
+    if (act) {
+      sh.are[e] = re;
+      sh.aim[e] = im;
+    }
+    __syncthreads();
+    double ar = 0.0, ai = 0.0, vr = 0.0, vi = 0.0;
+    if (act) {
+      if (i > j) {
+        ar = re;
+        ai = im;
+      } else if (i == j) {
+        ar = re;
+      } else {
+        ar = sh.are[j * DC + i];
+        ai = -sh.aim[j * DC + i];
+      }
+      vr = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    int cur = 0;
+    if (act) {
+      sh.are[e] = ar;
+      sh.aim[e] = ai;
+      sh.vre[0][e] = vr;
+      sh.vim[0][e] = vi;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 20; ++sweep) {
+      const double n2 = act ? ar * ar + ai * ai : 0.0;
+      const double off = block_sum<NT>((act && i != j) ? n2 : 0.0, sh.red);
+      const double nrm = block_sum<NT>(n2, sh.red);
+      if (!(off > 1e-30 * nrm)) break;
+      for (int r = 0; r < DC - 1; ++r) {
+        if (threadIdx.x < DC / 2) {
+          const int t = threadIdx.x;
+          int pa, pb;
+          if (t == 0) {
+            pa = DC - 1;
+            pb = r;
+          } else {
+            pa = (r + t) % (DC - 1);
+            pb = (r - t + (DC - 1)) % (DC - 1);
+          }
+          const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
+          const double app = sh.are[p * DC + p], aqq = sh.are[q * DC + q];
+          const double xr = sh.are[p * DC + q], xi = sh.aim[p * DC + q];
+          const double ab = hypot(xr, xi);
+          double cs = 1.0, sn = 0.0, er = 1.0, ei = 0.0;
+          if (ab > 1e-290) {
+            const double tau = (aqq - app) / (2.0 * ab);
+            const double tt = copysign(1.0, tau) / (fabs(tau) + hypot(1.0, tau));
+            cs = 1.0 / sqrt(1.0 + tt * tt);
+            sn = tt * cs;
+            er = xr / ab;
+            ei = xi / ab;
+          }
+          sh.rc[p] = cs;
+          sh.rc[q] = cs;
+          sh.ore[p] = -sn * er;
+          sh.oim[p] = sn * ei;
+          sh.ore[q] = sn * er;
+          sh.oim[q] = sn * ei;
+        }
+        __syncthreads();
+        double t_r = 0.0, t_i = 0.0;
+        int pi = 0;
+        double ci = 1.0, oir = 0.0, oii = 0.0;
+        if (act) {
+          const int pj = partner(j, r);
+          pi = partner(i, r);
+          const double cj = sh.rc[j], ojr = sh.ore[j], oji = sh.oim[j];
+          ci = sh.rc[i];
+          oir = sh.ore[i];
+          oii = sh.oim[i];
+          const double br = sh.are[i * DC + pj], bi = sh.aim[i * DC + pj];
+          t_r = ar * cj + (br * ojr - bi * oji);
+          t_i = ai * cj + (br * oji + bi * ojr);
+          const double wr = sh.vre[cur][i * DC + pj], wi = sh.vim[cur][i * DC + pj];
+          const double nvr = vr * cj + (wr * ojr - wi * oji);
+          const double nvi = vi * cj + (wr * oji + wi * ojr);
+          vr = nvr;
+          vi = nvi;
+          sh.tre[e] = t_r;
+          sh.tim[e] = t_i;
+          sh.vre[cur ^ 1][e] = vr;
+          sh.vim[cur ^ 1][e] = vi;
+        }
+        cur ^= 1;
+        __syncthreads();
+        if (act) {
+          const double ur = sh.tre[pi * DC + j], ui = sh.tim[pi * DC + j];
+          ar = ci * t_r + (oir * ur + oii * ui);  // ci T_ij + conj(o_i) T[pi][j]
+          ai = ci * t_i + (oir * ui - oii * ur);
+          if (j == pi) {
+            ar = 0.0;
+            ai = 0.0;
+          }
+          if (i == j) ai = 0.0;
+          sh.are[e] = ar;
+          sh.aim[e] = ai;
+        }
+        __syncthreads();
+      }
+    }
+    if (act) {
+      double rr = 0.0, ri = 0.0;
+      for (int k = 0; k < DC; ++k) {
+        const double lam = sh.are[k * DC + k];
+        const double lc = lam > eps ? lam : eps;
+        const double xr = sh.vre[cur][i * DC + k], xi = sh.vim[cur][i * DC + k];
+        const double yr = sh.vre[cur][j * DC + k], yi = sh.vim[cur][j * DC + k];
+        rr += lc * (xr * yr + xi * yi);  // V_ik conj(V_jk)
+        ri += lc * (xi * yr - xr * yi);
+      }
+      re = rr;
+      im = ri;
+    }
+    __syncthreads();
+  }
+
+  // TP projection (process.py:259-265) of the matrix whose element (i, j) this thread holds:
+  // C[(a,o),(b,o)] += (delta_ab - sum_o' C[(a,o'),(b,o')]) / d ; other entries unchanged.
+  __device__ static void tp_project(Sh& sh, bool act, int i, int j, double& re, double& im) {
+    const int e = i * DC + j;
+    if (act) {
+      sh.tre[e] = re;
+      sh.tim[e] = im;
+    }
+    __syncthreads();
+    if (threadIdx.x < DQ * DQ) {
+      const int a = threadIdx.x / DQ, b = threadIdx.x % DQ;
+      double sr = 0.0, si = 0.0;
+      for (int o = 0; o < DQ; ++o) {
+        sr += sh.tre[(a * DQ + o) * DC + (b * DQ + o)];
+        si += sh.tim[(a * DQ + o) * DC + (b * DQ + o)];
+      }
+      sh.rre[threadIdx.x] = sr;
+      sh.rim[threadIdx.x] = si;
+    }
+    __syncthreads();
+    if (act) {
+      const int a = i / DQ, o = i % DQ, b = j / DQ, o2 = j % DQ;
+      if (o == o2) {
+        re += ((a == b ? 1.0 : 0.0) - sh.rre[a * DQ + b]) / DQ;
+        im += (0.0 - sh.rim[a * DQ + b]) / DQ;
+      }
+    }
+    __syncthreads();
+  }
+
+  // Dykstra alternation (process.py:237-257).  x = this thread's element; returns iterations.
+  __device__ static int dykstra(Sh& sh, bool act, int i, int j, double& xr, double& xi, int n_iter, double tol) {
+    double pr = 0.0, pim = 0.0, qr = 0.0, qi = 0.0, yr = 0.0, yi = 0.0;
+    int it = 0;
+    for (; it < n_iter; ++it) {
+      double tr_ = xr + pr, ti_ = xi + pim;
+      tp_project(sh, act, i, j, tr_, ti_);
+      const double ydr = tr_ - yr, ydi = ti_ - yi;
+      yr += ydr;
+      yi += ydi;
+      double cr = yr + qr, ci = yi + qi;
+      cp_project(sh, act, i, j, cr, ci, 1e-12);
+      const double xdr = cr - xr, xdi = ci - xi;
+      xr += xdr;
+      xi += xdi;
+      // 2 (|sum conj(y_diff) q| + |sum conj(x_diff) p|)
+      const double s1r = block_sum<NT>(act ? ydr * qr + ydi * qi : 0.0, sh.red);
+      const double s1i = block_sum<NT>(act ? ydr * qi - ydi * qr : 0.0, sh.red);
+      const double s2r = block_sum<NT>(act ? xdr * pr + xdi * pim : 0.0, sh.red);
+      const double s2i = block_sum<NT>(act ? xdr * pim - xdi * pr : 0.0, sh.red);
+      double crit = 2.0 * (hypot(s1r, s1i) + hypot(s2r, s2i));
+      const double pdr = xr - yr, pdi = xi - yi;
+      pr += pdr;
+      pim += pdi;
+      const double qdr = yr - xr, qdi = yi - xi;
+      qr += qdr;
+      qi += qdi;
+      const double np2 = block_sum<NT>(act ? pdr * pdr + pdi * pdi : 0.0, sh.red);
+      const double nq2 = block_sum<NT>(act ? qdr * qdr + qdi * qdi : 0.0, sh.red);
+      crit += np2 + nq2;
+      if (crit < tol) {
+        ++it;
+        break;
+      }
+    }
+    return it;
+  }
+};
+
+// counts[B][D][M] -> choi[B][DC][DC]; DC = D = 4^n.  pinvT = [D*M][DC*DC] complex (row r of the
+// design matrix along the slow axis so that threads read consecutive Choi-vector entries).
+template <int DC>
+__global__ void __launch_bounds__(ProcWG<DC>::NT) k_lifp_batch(const int64_t* __restrict__ counts, int B, int M,
+                                                              const double* __restrict__ pinvT, int cptp,
+                                                              double* __restrict__ choi, int32_t* __restrict__ iters,
+                                                              int32_t* __restrict__ status) {
+  using W = ProcWG<DC>;
+  __shared__ typename W::Sh sh;
+  extern __shared__ double sfreq[];  // [DC * M]
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int tid = threadIdx.x;
+  const bool act = tid < W::NE;
+  const int64_t* cb = counts + (size_t)b * DC * M;
+  for (int s = 0; s < DC; ++s) {  // per-input-state frequencies (process.py:285)
+    double part = 0.0;
+    for (int m = tid; m < M; m += W::NT) part += (double)cb[s * M + m];
+    const double tot = block_sum<W::NT>(part, sh.red);
+    for (int m = tid; m < M; m += W::NT) sfreq[s * M + m] = (double)cb[s * M + m] / tot;
+  }
+  __syncthreads();
+  // thread tid = Choi-vector entry v = col * DC + row  ->  element (row, col)
+  double xr = 0.0, xi = 0.0;
+  const int row = tid % DC, col = tid / DC;
+  if (act) {
+    const double* p = pinvT + (size_t)tid * 2;
+    const int R = DC * M;
+#pragma unroll 4
+    for (int r = 0; r < R; ++r) {
+      const double f = sfreq[r];
+      xr += p[(size_t)r * W::NE * 2] * f;
+      xi += p[(size_t)r * W::NE * 2 + 1] * f;
+    }
+  }
+  // re-distribute so that thread (i, j) = (tid / DC, tid % DC) holds C[i][j]: C[row][col] sits in
+  // thread col*DC+row, i.e. the transposed position
+  __syncthreads();
+  if (act) {
+    sh.tre[row * DC + col] = xr;
+    sh.tim[row * DC + col] = xi;
+  }
+  __syncthreads();
+  const int i = tid / DC, j = tid % DC;
+  if (act) {
+    xr = sh.tre[tid];
+    xi = sh.tim[tid];
+  }
+  __syncthreads();
+  int it = 0;
+  if (cptp) it = W::dykstra(sh, act, i, j, xr, xi, 1000, 1e-12);
+  if (act) {
+    double* out = choi + ((size_t)b * W::NE + tid) * 2;
+    out[0] = xr;
+    out[1] = xi;
+  }
+  if (tid == 0) {
+    if (iters) iters[b] = it;
+    if (status) status[b] = (xr == xr) ? 0 : 4;
+  }
+}
+
+// mode 0: Dykstra CPTP, 1: TP only, 2: CP only  (process.py:231-278)
+template <int DC>
+__global__ void __launch_bounds__(ProcWG<DC>::NT) k_cptp_project(const double* __restrict__ in, int B, int mode,
+                                                                int n_iter, double tol, double* __restrict__ out,
+                                                                int32_t* __restrict__ iters) {
+  using W = ProcWG<DC>;
+  __shared__ typename W::Sh sh;
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int tid = threadIdx.x;
+  const bool act = tid < W::NE;
+  const int i = tid / DC, j = tid % DC;
+  double xr = 0.0, xi = 0.0;
+  if (act) {
+    xr = in[((size_t)b * W::NE + tid) * 2];
+    xi = in[((size_t)b * W::NE + tid) * 2 + 1];
+  }
+  int it = 0;
+  if (mode == 0) it = W::dykstra(sh, act, i, j, xr, xi, n_iter, tol);
+  else if (mode == 1) W::tp_project(sh, act, i, j, xr, xi);
+  else W::cp_project(sh, act, i, j, xr, xi, 1e-12);
+  if (act) {
+    out[((size_t)b * W::NE + tid) * 2] = xr;
+    out[((size_t)b * W::NE + tid) * 2 + 1] = xi;
+  }
+  if (tid == 0 && iters) iters[b] = it;
+}
 
 }  // namespace qt

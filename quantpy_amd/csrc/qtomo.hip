@@ -70,7 +70,7 @@ struct qt_handle {
   int S = 0, K = 0, M = 0;
   DevBuf A, AT, Aw, AwT, Pinv, PinvT, Ns, aug, info;
   // staging for host-pointer calls
-  DevBuf in0, in1, out0, out1, out2, out3, out4;
+  DevBuf in0, in1, out0, out1, out2, out3, out4, proc_aug;
   // process tomography
   qt::ProcessState proc;
   bool proc_set = false;
@@ -215,7 +215,7 @@ void qt_destroy(qt_handle_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->in0, &h->in1,
-                    &h->out0, &h->out1, &h->out2, &h->out3, &h->out4})
+                    &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug})
     b->release();
   h->proc.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -544,25 +544,146 @@ int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, in
   return finish(h, flags);
 }
 
-// ---- process tomography: see qt_process.h -----------------------------------------------------
+// ---- a5 for arbitrary matrices: routines.py:69-71 -------------------------------------------------
+int qt_left_inverse(qt_handle_t* h, const double* A, int rows, int cols, int is_complex, double* out, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (!A || !out || rows < 1 || cols < 1) return fail(QT_ERR_ARG, "bad left_inverse arguments");
+  if (rows < cols) return fail(QT_ERR_SINGULAR, "matrix has fewer rows (%d) than columns (%d)", rows, cols);
+  const int W = is_complex ? 2 : 1;
+  const size_t nel = (size_t)rows * cols * W;
+  const double* dA;
+  double* dout;
+  if (int r = stage_in(h, h->in0, A, nel, flags, &dA)) return r;
+  if (int r = stage_out(h, h->out0, out, nel, flags, &dout)) return r;
+  DevBuf& aug = h->proc_aug;
+  HIPCHK(aug.ensure((size_t)cols * 2 * cols * W * sizeof(double)));
+  HIPCHK(h->info.ensure(sizeof(int)));
+  double* g = aug.as<double>();
+  dim3 gg((cols + 15) / 16, (cols + 15) / 16), gp((rows + 15) / 16, (cols + 15) / 16);
+  if (is_complex) {
+    hipLaunchKernelGGL(qt::k_gemm<1>, gg, dim3(256), 0, h->stream, cols, cols, rows, dA, cols, 1, dA, cols, 0, g, 2 * cols);
+    hipLaunchKernelGGL(qt::k_gauss_jordan<1>, dim3(1), dim3(1024), 0, h->stream, cols, g, h->info.as<int>());
+    hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(256), 0, h->stream, cols, rows, cols, g + (size_t)cols * 2, 2 * cols, 0, dA,
+                       cols, 1, dout, rows);
+  } else {
+    hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(256), 0, h->stream, cols, cols, rows, dA, cols, 1, dA, cols, 0, g, 2 * cols);
+    hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, cols, g, h->info.as<int>());
+    hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(256), 0, h->stream, cols, rows, cols, g + cols, 2 * cols, 0, dA, cols, 1,
+                       dout, rows);
+  }
+  int info = 0;
+  HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (int r = fetch_out(h, dout, out, nel, flags)) return r;
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (info != 0) return fail(QT_ERR_SINGULAR, "A^T A is singular (no pivot in column %d)", info - 1);
+  return 0;
+}
+
+// ---- process tomography: qt_process.h -------------------------------------------------------------
 int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
   if (int r = check_handle(h)) return r;
   if (int r = need_povm(h)) return r;
-  (void)in_states;
-  (void)flags;
-  return fail(QT_ERR_UNSUPPORTED, "process tomography kernels are not built yet");
+  if (!in_states) return fail(QT_ERR_ARG, "null in_states");
+  if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "process tomography supports n_qubits 1..2 in this release");
+  h->proc_set = false;
+  const int d = h->d, D = h->D, M = h->M;
+  const size_t C2 = (size_t)D * D, R = (size_t)D * M;
+  qt::ProcessState& ps = h->proc;
+  ps.release();
+  HIPCHK(hipMalloc(&ps.in_states, (size_t)D * D * 2 * sizeof(double)));
+  HIPCHK(hipMalloc(&ps.emats, (size_t)M * D * 2 * sizeof(double)));
+  HIPCHK(hipMalloc(&ps.lifp, R * C2 * 2 * sizeof(double)));
+  HIPCHK(hipMalloc(&ps.pinv, R * C2 * 2 * sizeof(double)));
+  HIPCHK(hipMalloc(&ps.pinvT, R * C2 * 2 * sizeof(double)));
+  HIPCHK(hipMalloc(&ps.aug, C2 * 2 * C2 * 2 * sizeof(double)));
+  HIPCHK(h->info.ensure(sizeof(int)));
+  HIPCHK(hipMemcpyAsync(ps.in_states, in_states, (size_t)D * D * 2 * sizeof(double),
+                        (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  double *lifp = (double*)ps.lifp, *pinv = (double*)ps.pinv, *pinvT = (double*)ps.pinvT, *aug = (double*)ps.aug;
+  // E_m = sum_k A'[m][k] P_k  (process.py:204: Qobj(povm_bloch).matrix)
+  hipLaunchKernelGGL(qt::k_mat_from_bloch, dim3(grid_for((size_t)M * D)), dim3(256), 0, h->stream, h->nq, h->Aw.as<double>(),
+                     M, (double*)ps.emats);
+  hipLaunchKernelGGL(qt::k_lifp_rows, dim3(grid_for(R * C2)), dim3(256), 0, h->stream, d, M, (const double*)ps.in_states,
+                     (const double*)ps.emats, lifp);
+  const int c2 = (int)C2, rr = (int)R;
+  dim3 gg((c2 + 15) / 16, (c2 + 15) / 16), gp((rr + 15) / 16, (c2 + 15) / 16);
+  hipLaunchKernelGGL(qt::k_gemm<1>, gg, dim3(256), 0, h->stream, c2, c2, rr, lifp, c2, 1, lifp, c2, 0, aug, 2 * c2);
+  hipLaunchKernelGGL(qt::k_gauss_jordan<1>, dim3(1), dim3(1024), 0, h->stream, c2, aug, h->info.as<int>());
+  hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(256), 0, h->stream, c2, rr, c2, aug + (size_t)c2 * 2, 2 * c2, 0, lifp, c2, 1,
+                     pinv, rr);
+  hipLaunchKernelGGL(qt::k_transpose_c, dim3(grid_for(R * C2)), dim3(256), 0, h->stream, pinv, c2, rr, pinvT);
+  int info = 0;
+  HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (info != 0) return fail(QT_ERR_SINGULAR, "process design matrix is rank deficient (column %d): input states x POVM not complete", info - 1);
+  h->proc_set = true;
+  return 0;
 }
-int qt_process_get_operators(qt_handle_t* h, double*, double*, int) {
+
+int qt_process_get_operators(qt_handle_t* h, double* lifp_oper, double* lifp_oper_inv, int flags) {
   if (int r = check_handle(h)) return r;
-  return fail(QT_ERR_UNSUPPORTED, "process tomography kernels are not built yet");
+  if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
+  const size_t bytes = (size_t)h->D * h->M * h->D * h->D * 2 * sizeof(double);
+  const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (lifp_oper) HIPCHK(hipMemcpyAsync(lifp_oper, h->proc.lifp, bytes, kind, h->stream));
+  if (lifp_oper_inv) HIPCHK(hipMemcpyAsync(lifp_oper_inv, h->proc.pinv, bytes, kind, h->stream));
+  return finish(h, flags);
 }
-int qt_lifp_batch(qt_handle_t* h, const int64_t*, int, int, double*, int32_t*, int32_t*, int) {
+
+int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double* choi, int32_t* iters, int32_t* status,
+                  int flags) {
   if (int r = check_handle(h)) return r;
-  return fail(QT_ERR_UNSUPPORTED, "process tomography kernels are not built yet");
+  if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
+  if (B < 0 || (B > 0 && (!counts || !choi))) return fail(QT_ERR_ARG, "bad lifp_batch arguments");
+  if (B == 0) return 0;
+  const int D = h->D, M = h->M;
+  const int64_t* dc;
+  double* dchoi;
+  int32_t *dit, *dst;
+  if (int r = stage_in(h, h->in0, counts, (size_t)B * D * M, flags, &dc)) return r;
+  if (int r = stage_out(h, h->out0, choi, (size_t)B * D * D * 2, flags, &dchoi)) return r;
+  if (int r = stage_out(h, h->out1, iters, (size_t)B, flags, &dit)) return r;
+  if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
+  const size_t dyn = (size_t)D * M * sizeof(double);
+  if (dyn > 32 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the process kernel");
+  if (D == 4)
+    hipLaunchKernelGGL(qt::k_lifp_batch<4>, dim3(B), dim3(qt::ProcWG<4>::NT), dyn, h->stream, dc, B, M,
+                       (const double*)h->proc.pinvT, cptp, dchoi, dit, dst);
+  else
+    hipLaunchKernelGGL(qt::k_lifp_batch<16>, dim3(B), dim3(qt::ProcWG<16>::NT), dyn, h->stream, dc, B, M,
+                       (const double*)h->proc.pinvT, cptp, dchoi, dit, dst);
+  if (int r = fetch_out(h, dchoi, choi, (size_t)B * D * D * 2, flags)) return r;
+  if (int r = fetch_out(h, dit, iters, (size_t)B, flags)) return r;
+  if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
+  if (int r = finish(h, flags)) return r;
+  return count_bad(status, B, flags);
 }
-int qt_cptp_project_batch(qt_handle_t* h, const double*, int, int, int, double, double*, int32_t*, int) {
+
+int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode, int n_iter, double tol, double* choi_out,
+                          int32_t* iters, int flags) {
   if (int r = check_handle(h)) return r;
-  return fail(QT_ERR_UNSUPPORTED, "process tomography kernels are not built yet");
+  if (B < 0 || (B > 0 && (!choi_in || !choi_out))) return fail(QT_ERR_ARG, "bad cptp_project arguments");
+  if (mode < 0 || mode > 2) return fail(QT_ERR_ARG, "mode must be 0 (CPTP), 1 (TP) or 2 (CP)");
+  if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "process tomography supports n_qubits 1..2 in this release");
+  if (B == 0) return 0;
+  const int D = h->D;
+  const double* din;
+  double* dout;
+  int32_t* dit;
+  if (int r = stage_in(h, h->in0, choi_in, (size_t)B * D * D * 2, flags, &din)) return r;
+  if (int r = stage_out(h, h->out0, choi_out, (size_t)B * D * D * 2, flags, &dout)) return r;
+  if (int r = stage_out(h, h->out1, iters, (size_t)B, flags, &dit)) return r;
+  if (D == 4)
+    hipLaunchKernelGGL(qt::k_cptp_project<4>, dim3(B), dim3(qt::ProcWG<4>::NT), 0, h->stream, din, B, mode, n_iter, tol, dout,
+                       dit);
+  else
+    hipLaunchKernelGGL(qt::k_cptp_project<16>, dim3(B), dim3(qt::ProcWG<16>::NT), 0, h->stream, din, B, mode, n_iter, tol,
+                       dout, dit);
+  if (int r = fetch_out(h, dout, choi_out, (size_t)B * D * D * 2, flags)) return r;
+  if (int r = fetch_out(h, dit, iters, (size_t)B, flags)) return r;
+  return finish(h, flags);
 }
 
 }  // extern "C"

@@ -1,0 +1,84 @@
+"""Sharding of independent tomography trials over the GPUs of a node.
+
+Trials / bootstrap resamples share only read-only operands, so each rank reconstructs a
+contiguous slice of the batch on its own GPU and the only exchange is one all-gather of the
+per-trial results (float64 distances: 16 KB for 2000 resamples) -- RCCL over xGMI when the
+process group is `nccl`, gloo in the CPU tests.  One process per GPU (torchrun); without an
+initialised process group everything degenerates to a single shard.
+"""
+import numpy as np
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except Exception:  # pragma: no cover - torch is part of the image
+        return None
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def world():
+    """(rank, world_size) of the default process group, (0, 1) when none is initialised."""
+    dist = _dist()
+    return (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+
+
+def shard_bounds(n_items, rank=None, world_size=None):
+    """Contiguous, balanced [lo, hi) slice of range(n_items) owned by `rank`; the first
+    n_items % world_size ranks get one extra item.  Empty slices are legal."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    base, extra = divmod(int(n_items), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def broadcast_array(array, src=0):
+    """Make every rank hold rank `src`'s ndarray (e.g. the counts drawn from rank 0's RNG stream)."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return array
+    import torch
+
+    dev = _comm_device()
+    t = torch.from_numpy(np.ascontiguousarray(array)).to(dev)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+def _comm_device():
+    import torch
+
+    dist = _dist()
+    if dist is not None and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def allgather_concat(local, n_total):
+    """Concatenate the ranks' 1-D float64 shards (in rank order) into the full length-`n_total`
+    vector on every rank.  Shards may differ in length by one; they are padded to the largest."""
+    dist = _dist()
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if dist is None or dist.get_world_size() == 1:
+        return local
+    import torch
+
+    ws = dist.get_world_size()
+    sizes = [shard_bounds(n_total, r, ws) for r in range(ws)]
+    width = max(hi - lo for lo, hi in sizes)
+    dev = _comm_device()
+    buf = torch.zeros(width, dtype=torch.float64, device=dev)
+    buf[: local.shape[0]] = torch.from_numpy(local).to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(ws)]
+    dist.all_gather(gathered, buf)
+    parts = [g[: hi - lo].cpu().numpy() for g, (lo, hi) in zip(gathered, sizes)]
+    return np.concatenate(parts)
+
+
+def sharded_map(items, fn):
+    """Apply `fn(items[lo:hi]) -> 1-D float64 array` to this rank's slice and all-gather."""
+    n = len(items)
+    lo, hi = shard_bounds(n)
+    local = fn(items[lo:hi]) if hi > lo else np.empty(0)
+    return allgather_concat(local, n)

@@ -142,6 +142,68 @@ class Engine:
         self._chk(self.lib.qt_get_left_inverse(self._h, _ptr(out), _capi.QT_HOST_PTR))
         return out
 
+    def left_inverse_of(self, a):
+        """inv(A^T A) A^T (plain transpose) of an arbitrary real or complex matrix."""
+        a = np.asarray(a)
+        cplx = np.iscomplexobj(a)
+        a = _c128(a) if cplx else _f64(a)
+        rows, cols = a.shape
+        out = np.empty((cols, rows), dtype=a.dtype)
+        self._chk(self.lib.qt_left_inverse(self._h, _ptr(a), rows, cols, int(cplx), _ptr(out), _capi.QT_HOST_PTR))
+        return out
+
+    # ---- a11 - a15: process tomography ---------------------------------------------------------
+    def process_setup(self, in_states):
+        """in_states (D, d, d) complex: design matrix + left inverse for the POVM of `set_povm`."""
+        s = _c128(in_states)
+        assert s.shape == (self.D, self.d, self.d)
+        key = (self._povm_key, s.tobytes())
+        if key == getattr(self, "_proc_key", None):
+            return
+        self._proc_key = None
+        self._chk(self.lib.qt_process_setup(self._h, _ptr(s), _capi.QT_HOST_PTR))
+        self._proc_key = key
+
+    def process_operators(self):
+        rows, cols = self.D * self.M, self.D * self.D
+        oper = np.empty((rows, cols), dtype=np.complex128)
+        inv = np.empty((cols, rows), dtype=np.complex128)
+        self._chk(self.lib.qt_process_get_operators(self._h, _ptr(oper), _ptr(inv), _capi.QT_HOST_PTR))
+        return oper, inv
+
+    def lifp(self, counts, cptp=True, return_iters=False):
+        """counts (B, D, S, K) or (D, S, K) -> Choi (B, D, D) / (D, D)."""
+        c = _i64(counts)
+        single = c.ndim == 3
+        c = c.reshape(-1, self.D, self.S, self.K)
+        b = c.shape[0]
+        choi = np.empty((b, self.D, self.D), dtype=np.complex128)
+        iters = np.zeros(b, dtype=np.int32)
+        status = np.zeros(b, dtype=np.int32)
+        self._chk(self.lib.qt_lifp_batch(self._h, _ptr(c), b, int(bool(cptp)), _ptr(choi), _ptr(iters), _ptr(status),
+                                         _capi.QT_HOST_PTR))
+        if single:
+            choi, iters = choi[0], iters[0]
+        return (choi, iters) if return_iters else choi
+
+    def lifp_dev(self, counts, choi, cptp=True, iters=None, status=None):
+        self._chk(self.lib.qt_lifp_batch(self._h, _ptr(counts), counts.shape[0], int(bool(cptp)), _ptr(choi), _ptr(iters),
+                                         _ptr(status), _capi.QT_DEVICE_PTR))
+
+    def cptp_project(self, choi, mode="cptp", n_iter=1000, tol=1e-12, return_iters=False):
+        """mode 'cptp' (Dykstra) | 'tp' | 'cp' on Choi matrices (B, D, D) / (D, D)."""
+        m = {"cptp": 0, "tp": 1, "cp": 2}[mode]
+        c = _c128(choi)
+        single = c.ndim == 2
+        c = c.reshape(-1, self.D, self.D)
+        out = np.empty_like(c)
+        iters = np.zeros(c.shape[0], dtype=np.int32)
+        self._chk(self.lib.qt_cptp_project_batch(self._h, _ptr(c), c.shape[0], m, int(n_iter), float(tol), _ptr(out),
+                                                 _ptr(iters), _capi.QT_HOST_PTR))
+        if single:
+            out, iters = out[0], iters[0]
+        return (out, iters) if return_iters else out
+
     # ---- a4 / a3 ----------------------------------------------------------------------------
     def born_probs(self, bloch, out=None):
         if _is_dev(bloch):

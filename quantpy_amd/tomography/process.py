@@ -1,0 +1,129 @@
+"""Quantum process tomography with quantpy's API (reference quantpy/tomography/process.py).
+
+A process is probed by preparing each state of an input basis, applying the channel and doing
+state tomography on the output.  Counts are simulated on the host (same RNG order as the
+reference: input state by input state, POVM setting by setting); the estimator -- design
+matrix, its left inverse, Choi linear inversion and the Dykstra CPTP projection -- runs on the
+GPU (qt_process_setup / qt_lifp_batch / qt_cptp_project_batch).
+"""
+import numpy as np
+
+from ..basis import Basis
+from ..channel import Channel
+from ..engine import get_engine
+from ..measurements import generate_measurement_matrix
+from ..qobj import Qobj
+from ..routines import _mat2vec, _out_ptrace_oper, _vec2mat, generate_single_entries
+from .state import StateTomograph, _resolve_dst
+
+
+def _generate_input_states(input_states, n_qubits):
+    """Named POVM -> its rows as trace-normalised states; a list is taken as given."""
+    if isinstance(input_states, list):
+        return input_states
+    states = []
+    for bloch in np.squeeze(generate_measurement_matrix(input_states, n_qubits)):
+        state = Qobj(bloch)
+        state /= state.trace()
+        states.append(state)
+    return states
+
+
+class ProcessTomograph:
+    """Simulate and reconstruct the tomography of `channel`.
+
+    Parameters
+    ----------
+    channel : Channel
+    input_states : name of a POVM whose rows define the input states ('proj4' default) or a list
+        of Qobj; must span the operator space (4^n elements), else ValueError.
+    dst : 'hs' | 'trace' | 'if' | callable
+    """
+
+    def __init__(self, channel, input_states="proj4", dst="hs"):
+        self.channel = channel
+        self.dst = _resolve_dst(dst)
+        self.input_states = input_states
+        self.input_basis = Basis(_generate_input_states(input_states, channel.n_qubits))
+        if self.input_basis.dim != 4**channel.n_qubits:
+            raise ValueError("Input states do not constitute a basis")
+        self._decomposed_single_entries = np.array(
+            [self.input_basis.decompose(Qobj(unit)) for unit in generate_single_entries(2**channel.n_qubits)])
+        self._ptrace_oper = _out_ptrace_oper(channel.n_qubits)
+        self._ptrace_dag_ptrace = self._ptrace_oper.T.conj() @ self._ptrace_oper
+
+    # ---- data -------------------------------------------------------------------------------------
+    def experiment(self, n_measurements, povm="proj-set", warm_start=False):
+        """State tomography of channel(rho_in) for every input state, in basis order."""
+        if not warm_start:
+            self.tomographs = [StateTomograph(self.channel.transform(state)) for state in self.input_basis.elements]
+        for tmg in self.tomographs:
+            tmg.experiment(n_measurements, povm, warm_start=warm_start)
+
+    @property
+    def results(self):
+        assert hasattr(self, "tomographs"), "No results"
+        return np.asarray([tmg.results for tmg in self.tomographs])
+
+    @results.setter
+    def results(self, results):
+        assert hasattr(self, "tomographs"), "Call experiment first"
+        for tmg, counts in zip(self.tomographs, results):
+            tmg.results = counts
+
+    # ---- estimators -------------------------------------------------------------------------------
+    def _engine(self):
+        first = self.tomographs[0]
+        eng = get_engine(self.channel.n_qubits)
+        eng.set_povm(first.povm_matrix, first.n_measurements)
+        eng.process_setup(np.stack([np.asarray(s.matrix, dtype=np.complex128) for s in self.input_basis.elements]))
+        return eng
+
+    def point_estimate(self, method="lifp", cptp=True, n_iter=1000, tol=1e-10, states_est_method="lin",
+                       states_physical=True, states_init="lin"):
+        """method 'lifp': Choi matrix by linear inversion of all frequencies at once, then (if
+        `cptp`) the alternating projection onto completely positive trace-preserving maps.
+        'pgdb' and 'states' of the reference are not on the GPU hot path."""
+        if method != "lifp":
+            if method in ("pgdb", "states"):
+                raise NotImplementedError(f"method={method!r} is not part of the GPU hot path")
+            raise ValueError("Incorrect value for argument `method`")
+        eng = self._engine()
+        self._unnorm_results = np.hstack([tmg.flat_results for tmg in self.tomographs])
+        self.frequencies = np.hstack([tmg.flat_results / tmg.flat_results.sum() for tmg in self.tomographs])
+        choi, iters = eng.lifp(self.results, cptp=cptp, return_iters=True)
+        self.cptp_iterations = int(iters)
+        self.reconstructed_channel = Channel(choi)
+        return self.reconstructed_channel
+
+    def point_estimate_batch(self, counts, cptp=True):
+        """Extension: counts (B, D, S, K) -> Choi matrices (B, D, D) in one launch."""
+        return self._engine().lifp(np.asarray(counts), cptp=cptp)
+
+    @property
+    def _lifp_oper(self):
+        return self._engine().process_operators()[0]
+
+    @property
+    def _lifp_oper_inv(self):
+        return self._engine().process_operators()[1]
+
+    def _project(self, channel, mode, vectorized, **kw):
+        eng = get_engine(channel.n_qubits)
+        out = eng.cptp_project(np.asarray(channel.choi.matrix, dtype=np.complex128), mode=mode, **kw)
+        return _mat2vec(out) if vectorized else Channel(out)
+
+    def cptp_projection(self, channel, n_iter=1000, tol=1e-12):
+        """Dykstra alternating projection of `channel` onto CPTP maps."""
+        return self._project(channel, "cptp", False, n_iter=n_iter, tol=tol)
+
+    def _cptp_projection_vec(self, choi_vec, n_iter=1000, tol=1e-12):
+        return self._project(Channel(_vec2mat(np.asarray(choi_vec))), "cptp", True, n_iter=n_iter, tol=tol)
+
+    def tp_projection(self, channel, vectorized=False):
+        """Affine projection onto trace-preserving maps: Tr_out C = I."""
+        return self._project(channel, "tp", vectorized)
+
+    def cp_projection(self, channel, vectorized=False):
+        """Projection onto completely positive maps: eigenvalues of C clipped at 1e-12."""
+        return self._project(channel, "cp", vectorized)

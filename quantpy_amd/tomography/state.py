@@ -1,0 +1,136 @@
+"""Quantum state tomography with quantpy's API (reference quantpy/tomography/state.py).
+
+`experiment()` simulates counts on the host with NumPy's legacy global RNG in the reference's
+call order (one multinomial per POVM setting), so a seed reproduces the reference's counts
+bit for bit; `point_estimate()` hands the counts to the HIP engine (qt_lin_batch /
+qt_mle_batch).  There is no CPU estimator in this package.
+"""
+import numpy as np
+
+from ..engine import get_engine
+from ..geometry import hs_dst, if_dst, trace_dst
+from ..measurements import generate_measurement_matrix
+from ..qobj import Qobj
+
+_DISTANCES = {"hs": hs_dst, "trace": trace_dst, "if": if_dst}
+
+
+def _resolve_dst(dst):
+    if isinstance(dst, str):
+        if dst not in _DISTANCES:
+            raise ValueError("Invalid value for argument `dst`")
+        return _DISTANCES[dst]
+    return dst
+
+
+def simulate_counts(povm_matrix, bloch, n_measurements):
+    """Born probabilities + multinomial draws for one state (reference state.py:109-114).
+
+    The probabilities that feed the sampler are evaluated on the host with the reference's own
+    NumPy expression: the legacy binomial behind np.random.multinomial branches on p <= 0.5, and
+    structured states put conditional probabilities exactly there, so the last bit of p decides
+    the draw.  (The GPU Born-rule kernel qt_born_probs serves batched probability evaluation,
+    where that bit does not matter.)
+    """
+    dim = int(round(np.sqrt(povm_matrix.shape[-1])))
+    probas = np.einsum("ijk,k->ij", povm_matrix, bloch) * dim
+    probas = np.clip(probas, 0, 1)
+    return np.asarray([np.random.multinomial(n, p) for p, n in zip(probas, n_measurements)])
+
+
+class StateTomograph:
+    """Simulate measurements of `state` and reconstruct its density matrix.
+
+    Parameters
+    ----------
+    state : Qobj
+    dst : 'hs' | 'trace' | 'if' | callable(Qobj, Qobj) -> float
+
+    Attributes set by `experiment()`: povm_matrix (S, K, 4^n), results (S, K) int,
+    n_measurements (S,), and by `point_estimate()`: reconstructed_state.
+    """
+
+    def __init__(self, state, dst="hs"):
+        self.state = state
+        self.dst = _resolve_dst(dst)
+        self._results = None
+
+    # ---- data ---------------------------------------------------------------------------------
+    def experiment(self, n_measurements, povm="proj-set", warm_start=False):
+        """Draw measurement outcomes.
+
+        n_measurements : integer (shots per POVM setting) or one entry per setting.  A float
+            scalar is rejected exactly like the reference does (TypeError from len()).
+        povm : name or array, see `generate_measurement_matrix`.
+        warm_start : append to the data of the previous call instead of replacing it.
+        """
+        povm_matrix = generate_measurement_matrix(povm, self.state.n_qubits)
+        n_settings = povm_matrix.shape[0]
+        if np.issubdtype(type(n_measurements), np.integer):
+            n_measurements = np.ones(n_settings) * n_measurements
+        elif len(n_measurements) != n_settings:
+            raise ValueError("Wrong length for argument `n_measurements`")
+        counts = simulate_counts(povm_matrix, self.state.bloch, n_measurements)
+        if warm_start:
+            old_total, new_total = np.sum(self.n_measurements), np.sum(n_measurements)
+            self.povm_matrix = np.vstack((self.povm_matrix * old_total, povm_matrix * new_total)) / (old_total + new_total)
+            self.results = np.vstack((self.results, counts))  # the setter recomputes n_measurements
+        else:
+            self.povm_matrix = povm_matrix
+            self.results = counts
+            self.n_measurements = np.asarray(n_measurements)
+
+    @property
+    def results(self):
+        return self._results
+
+    @results.setter
+    def results(self, results):
+        self._results = results
+        self.n_measurements = results.sum(-1)
+
+    @property
+    def flat_results(self):
+        return self.results.flatten()
+
+    # ---- estimators ---------------------------------------------------------------------------
+    def _engine(self):
+        eng = get_engine(self.state.n_qubits)
+        eng.set_povm(self.povm_matrix, self.n_measurements)
+        return eng
+
+    def point_estimate(self, method="lin", physical=True, init="lin", max_iter=100, tol=1e-3):
+        """Reconstruct the density matrix on the GPU.
+
+        method : 'lin' -- linear inversion in the Pauli basis (+ eigenvalue clip at 1e-15 and
+                 trace renormalisation when `physical`);
+                 'mle' -- Cholesky-parametrised maximum likelihood, BFGS with scipy's control
+                 flow (gtol = `tol` in the inf-norm, `max_iter` iterations), started from the
+                 physical 'lin' estimate (`init='lin'`) or the fully mixed state ('mixed').
+        Returns the Qobj, also stored in `reconstructed_state`.
+        """
+        if method == "lin":
+            rho = self._engine().lin(self.results, physical=physical)
+        elif method == "mle":
+            if init not in ("lin", "mixed"):
+                raise ValueError("Invalid value for argument `init`")
+            rho, info = self._engine().mle(self.results, init=init, max_iter=max_iter, tol=tol, return_info=True)
+            if info["status"] == 1:  # the reference fails inside scipy.linalg.cholesky here
+                raise np.linalg.LinAlgError("starting point of the MLE is not positive definite")
+            self.mle_info = info
+        elif method == "mle-constr":
+            raise NotImplementedError("'mle-constr' (SLSQP) is not part of the GPU hot path")
+        else:
+            raise ValueError("Invalid value for argument `method`")
+        self.reconstructed_state = Qobj(rho)
+        return self.reconstructed_state
+
+    def point_estimate_batch(self, counts, method="lin", physical=True, init="lin", max_iter=100, tol=1e-3):
+        """Extension: reconstruct many count tensors (B, S, K) measured with this tomograph's POVM
+        and shots in one launch.  Returns (rho (B, d, d), info dict or None)."""
+        eng = self._engine()
+        if method == "lin":
+            return eng.lin(np.asarray(counts), physical=physical), None
+        if method == "mle":
+            return eng.mle(np.asarray(counts), init=init, max_iter=max_iter, tol=tol, return_info=True)
+        raise ValueError("Invalid value for argument `method`")

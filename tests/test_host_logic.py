@@ -1,0 +1,209 @@
+"""CPU: host-side logic of the product (no GPU, no compute call into the library):
+Qobj conversions in the reference's rounding order, containers, gate zoo, sharding helpers,
+and that libqtomo.so loads and exports every symbol include/qtomo.h declares."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from conftest import ROOT, load_golden
+
+
+@pytest.fixture(scope="module")
+def qp():
+    import quantpy_amd
+
+    return quantpy_amd
+
+
+def test_library_exports_every_declared_symbol():
+    from quantpy_amd import _capi
+
+    header = open(os.path.join(ROOT, "include", "qtomo.h")).read()
+    declared = set(re.findall(r"\b(qt_[a-z0-9_]+)\s*\(", header))
+    declared -= {"qt_handle_t"}
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = _capi.load()  # attaches prototypes: AttributeError if a symbol is missing
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.qt_version() >= 100
+
+
+def test_no_gpu_means_loud_failure_not_fallback(qp):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(qp.EngineUnavailable):
+        qp.get_engine(1)
+    t = qp.StateTomograph(qp.qobj.zero(1))
+    np.random.seed(0)
+    t.experiment(10000)  # sampling is host logic
+    assert t.results.tolist() == [[5002, 4998], [5028, 4972], [10000, 0]]
+    with pytest.raises(qp.EngineUnavailable):
+        t.point_estimate("lin")
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "quantpy_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(import|from)\s+.*oracle", text, re.M) or "quantpy_oracle" in text:
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_qobj_conversions_bit_exact_with_reference(qp):
+    g = load_golden("states_born")
+    for n in (1, 2, 3, 4):
+        for rho, bloch, back in zip(g[f"rho_n{n}"], g[f"bloch_n{n}"], g[f"rho_from_bloch_n{n}"]):
+            assert np.array_equal(qp.Qobj(rho).bloch, bloch)
+            assert np.array_equal(qp.Qobj(bloch).matrix, back)
+        assert np.array_equal(qp.Qobj(g[f"nonherm_n{n}"]).bloch, g[f"nonherm_bloch_n{n}"])
+
+
+def test_qobj_container_semantics(qp):
+    q = qp.Qobj([0.5, 0, 0, 0.5])
+    assert q.n_qubits == 1 and np.allclose(q.matrix, [[1, 0], [0, 0]])
+    assert np.allclose(qp.Qobj([0.1, 0.2, 0.3]).bloch, [0.5, 0.1, 0.2, 0.3])  # identity component prepended
+    assert np.allclose(qp.Qobj([1, 0], is_ket=True).matrix, [[1, 0], [0, 0]])
+    q.matrix = np.eye(2) / 2
+    assert np.allclose(q.bloch, [0.5, 0, 0, 0])  # setter invalidated the cached Bloch vector
+    q.bloch = [0.5, 0.5, 0, 0]
+    assert np.allclose(q.matrix, [[0.5, 0.5], [0.5, 0.5]])
+    c = qp.Qobj(q)
+    c.matrix[0, 0] = 7
+    assert q.matrix[0, 0] == 0.5  # deep copy
+    with pytest.raises(ValueError):
+        qp.Qobj(np.zeros((2, 2, 2)))
+    ghz = qp.qobj.GHZ(3)
+    assert ghz.is_pure() and ghz.is_density_matrix() and abs(ghz.impurity()) < 1e-12
+    assert np.allclose(ghz.ptrace([0]).matrix, np.eye(2) / 2)
+    assert np.allclose(qp.qobj.GHZ(2).ptrace([0, 1]).matrix, qp.qobj.GHZ(2).matrix)
+    u, s, vh = qp.qobj.GHZ(2).schmidt()
+    assert np.allclose(s, [2**-0.5, 2**-0.5])
+    assert not qp.qobj.fully_mixed(2).is_pure()
+    with pytest.raises(ValueError):
+        qp.qobj.fully_mixed(1).ket()
+    assert (q + q) == q * 2 and (q - q) == q * 0 and (q / 2) == q * 0.5 and (-q) == q * -1 and (2 * q) == q * 2
+    assert q != q * 3
+    with pytest.raises(ValueError):
+        q * "a"
+    k = q.kron(qp.qobj.zero(1))
+    assert k.n_qubits == 2 and np.allclose(k.matrix, np.kron(q.matrix, qp.qobj.zero(1).matrix))
+    assert "Quantum object" in repr(q) and "equation" in q._repr_latex_()
+    assert np.allclose(qp.qobj.zero(1).T.matrix, qp.qobj.zero(1).matrix)
+    assert np.allclose(q.H.matrix, q.matrix.conj().T) and np.allclose(q.conj().matrix, q.matrix.conj())
+    assert np.allclose(qp.product(q, q), np.trace(q.matrix @ q.matrix.conj().T))
+
+
+def test_gates_and_channels(qp):
+    op = qp.operator
+    for gate in (op.X, op.Y, op.Z, op.H, op.T, op.S, op.CNOT, op.CY, op.CZ, op.SWAP, op.ISWAP, op.MS, op.Toffoli,
+                 op.Fredkin, op.RX(0.3), op.RY(0.4), op.RZ(0.5), op.PHASE(0.6)):
+        assert np.allclose(gate.matrix @ gate.matrix.conj().T, np.eye(gate.matrix.shape[0]))
+    assert np.allclose(op.CNOT.matrix[2:, 2:], op.X.matrix) and np.allclose(op.Toffoli.matrix[6:, 6:], op.X.matrix)
+    assert np.allclose(op.Fredkin.matrix[5:7, 5:7], op.X.matrix)
+    assert np.allclose((op.H @ op.Z @ op.H).matrix, op.X.matrix)
+    assert np.allclose(qp.join_gates([op.X, op.Z]).matrix, op.Z.matrix @ op.X.matrix)
+    plus = op.H.transform(qp.qobj.zero(1))
+    assert np.allclose(plus.matrix, np.full((2, 2), 0.5))
+    ch = op.H.as_channel()
+    assert ch.is_cptp(verbose=False) and ch.n_qubits == 1
+    assert np.allclose(qp.Channel(ch.choi).transform(qp.qobj.zero(1)).matrix, plus.matrix)  # Choi form
+    assert np.allclose(qp.Channel(ch.kraus).transform(qp.qobj.zero(1)).matrix, plus.matrix)  # Kraus form
+    dep = qp.channel.depolarizing(0.25, 1)
+    out = dep.transform(qp.qobj.zero(1))
+    assert np.allclose(out.matrix, [[0.875, 0], [0, 0.125]])
+    assert np.allclose(dep.choi.ptrace([0]).matrix, np.eye(2))
+    assert np.allclose(qp.channel.dephasing(0.5).transform(plus).matrix, np.eye(2) / 2)
+    ad = qp.channel.amplitude_damping(0.3)
+    assert ad.is_cptp(verbose=False)
+    assert np.allclose(ad.transform(qp.Qobj([0, 1], is_ket=True)).matrix, [[0.3, 0], [0, 0.7]])
+    assert qp.channel.walsh_hadamard(2).is_cptp(verbose=False)
+    assert np.allclose(qp.channel.depolarize(ch, 1.0).choi.matrix, qp.channel.depolarizing(1, 1).choi.matrix)
+    assert not qp.Channel(np.diag([1.0, 0, 0, -1.0])).is_cptp(verbose=False)
+    with pytest.raises(ValueError):
+        qp.Channel(lambda r: r)  # n_qubits is compulsory for a map
+    assert (dep + dep) == dep * 2 and (dep - dep) == dep * 0
+
+
+def test_basis_and_routines(qp, oracle):
+    from quantpy_amd import routines
+    from quantpy_amd.tomography.process import _generate_input_states
+
+    states = _generate_input_states("proj4", 1)
+    b = qp.basis.Basis(states)
+    assert b.dim == 4 and np.allclose(b.gram, b.gram.conj().T)
+    target = qp.Qobj(np.array([[0.3, 0.1 - 0.2j], [0.1 + 0.2j, 0.7]]))
+    coeffs = b.decompose(target)
+    assert np.allclose(b.compose(coeffs).matrix, target.matrix)
+    for n in (1, 2):
+        assert np.array_equal(routines._out_ptrace_oper(n), oracle.out_ptrace_oper(n))
+    m = np.arange(16).reshape(4, 4) + 1j
+    assert np.array_equal(routines._vec2mat(routines._mat2vec(m)), m)
+    assert np.array_equal(routines._mat2vec(m), oracle.mat2vec(m))
+    units = routines.generate_single_entries(2)
+    assert len(units) == 4 and units[1][0, 1] == 1 and units[1].sum() == 1
+    z = np.arange(6.0)
+    assert np.array_equal(routines._complex_to_real(routines._real_to_complex(z)), z)
+    assert len(qp.generate_pauli(1)) == 4  # the reference's one-qubit special case: a plain list
+    for name in ("proj", "proj-set", "proj4", "sic"):
+        assert np.array_equal(qp.generate_measurement_matrix(name, 1), oracle.measurement_matrix(name, 1))
+    full = np.ones((5, 16))
+    assert qp.generate_measurement_matrix(full, 2).shape == (1, 5, 16)
+
+
+def test_shard_bounds_cover_and_balance():
+    from quantpy_amd.distributed import shard_bounds
+
+    for n in (0, 1, 7, 8, 2000, 2001):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_GLOO_WORKER = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from quantpy_amd import distributed as qd
+dist.init_process_group("gloo")
+rank, ws = qd.world()
+n = int(sys.argv[2])
+items = np.arange(n * 3, dtype=np.int64).reshape(n, 3) if rank == 0 else np.zeros((n, 3), dtype=np.int64)
+items = qd.broadcast_array(items)            # every rank now holds rank 0's "counts"
+seen = []
+def fn(shard):
+    seen.append(len(shard))
+    return shard.sum(axis=1).astype(np.float64) * 0.5
+out = qd.sharded_map(items, fn)
+want = np.arange(n * 3).reshape(n, 3).sum(axis=1) * 0.5
+lo, hi = qd.shard_bounds(n)
+assert out.shape == (n,) and np.array_equal(out, want), (rank, out, want)
+assert sum(seen) == hi - lo
+print(f"rank {rank}/{ws} ok {hi - lo}", flush=True)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("n_items", [2000, 7, 1])
+def test_sharded_bootstrap_gather_gloo_world2(tmp_path, n_items):
+    """the N > 1 path: contiguous shards, one all-gather, identical result on every rank
+    (world_size 2, gloo, CPU)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29600 + n_items % 50), str(script), ROOT, str(n_items)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "rank 0/2 ok" in res.stdout and "rank 1/2 ok" in res.stdout

@@ -145,22 +145,21 @@ struct ProcWG {
           const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
           const double app = sh.are[p * DC + p], aqq = sh.are[q * DC + q];
           const double xr = sh.are[p * DC + q], xi = sh.aim[p * DC + q];
-          const double ab = hypot(xr, xi);
-          double cs = 1.0, sn = 0.0, er = 1.0, ei = 0.0;
-          if (ab > 1e-290) {
-            const double tau = (aqq - app) / (2.0 * ab);
-            const double tt = copysign(1.0, tau) / (fabs(tau) + hypot(1.0, tau));
-            cs = 1.0 / sqrt(1.0 + tt * tt);
-            sn = tt * cs;
-            er = xr / ab;
-            ei = xi / ab;
+          const double ab2 = xr * xr + xi * xi;
+          double cs = 1.0, wre = 0.0, wim = 0.0;  // w = s e^{i phi} = c u a_pq  (see qt_small.h)
+          if (ab2 > 1e-300) {
+            const double dl = 0.5 * (aqq - app);
+            const double u = copysign(1.0, dl) / (fabs(dl) + sqrt(dl * dl + ab2));
+            cs = 1.0 / sqrt(1.0 + u * u * ab2);
+            wre = cs * u * xr;
+            wim = cs * u * xi;
           }
           sh.rc[p] = cs;
           sh.rc[q] = cs;
-          sh.ore[p] = -sn * er;
-          sh.oim[p] = sn * ei;
-          sh.ore[q] = sn * er;
-          sh.oim[q] = sn * ei;
+          sh.ore[p] = -wre;
+          sh.oim[p] = wim;
+          sh.ore[q] = wre;
+          sh.oim[q] = wim;
         }
         __syncthreads();
         double t_r = 0.0, t_i = 0.0;

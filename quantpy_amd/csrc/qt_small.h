@@ -57,6 +57,64 @@ __device__ __forceinline__ double gmax(double v) {
   return v;
 }
 
+// 1/sqrt(x) and 1/x for normal-range positive x: hardware seed (v_rsq_f64 / v_rcp_f64) plus two
+// Newton steps -- ~8 dependent FP64 instructions instead of the ~25 of a correctly rounded
+// sqrt-then-divide, accurate to ~1 ulp, which is all a Jacobi rotation needs to stay unitary.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(y * e, fma(e, 0.375, 0.5), y);
+  e = fma(-x * y, y, 1.0);
+  return fma(y * e, 0.5, y);
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
+// sum_m base[m * stride + lane_off] * lds_vec[m], m < n: the matrix-vector products of the hot path.
+// `base`/`stride` are wave-uniform (scalar row base), `lane_off` is the lane's column.  The loads
+// of a block of UNR rows are issued back to back before any of them is consumed (the
+// sched_group_barriers pin that order: hipcc otherwise interleaves load / wait / FMA pairs and the
+// wave, alone on its SIMD, eats one L2 latency per pair), and four accumulators keep the FP64
+// FMAs from forming a single dependency chain.
+template <int UNR>
+__device__ __forceinline__ void dot_block(const double* __restrict__ base, size_t stride, unsigned lane_off,
+                                          const double* lds_vec, int m, double (&acc)[4]) {
+  double av[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) av[u] = base[(size_t)(m + u) * stride + lane_off];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) acc[u & 3] = fma(av[u], lds_vec[m + u], acc[u & 3]);
+  __builtin_amdgcn_sched_group_barrier(0x020, UNR, 0);  // all VMEM reads of the block first,
+#pragma unroll
+  for (int u = 0; u < UNR; u += 4) {                    // then LDS broadcast reads feeding FMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+  }
+}
+
+template <int UNR>
+__device__ __forceinline__ double dot_strided(const double* __restrict__ base, size_t stride, unsigned lane_off,
+                                              const double* lds_vec, int n) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  int m = 0;
+  for (; m + UNR <= n; m += UNR) dot_block<UNR>(base, stride, lane_off, lds_vec, m, acc);
+  if (UNR > 8 && m + 8 <= n) {
+    dot_block<8>(base, stride, lane_off, lds_vec, m, acc);
+    m += 8;
+  }
+  if (UNR > 4 && m + 4 <= n) {
+    dot_block<4>(base, stride, lane_off, lds_vec, m, acc);
+    m += 4;
+  }
+  for (; m < n; ++m) acc[0] = fma(base[(size_t)m * stride + lane_off], lds_vec[m], acc[0]);
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 struct PovmView {
   const double* Aw;    // [M][D]  shot-weighted A'
   const double* AwT;   // [D][M]
@@ -201,12 +259,8 @@ struct Small {
 
   // ---- a6: linear inversion.  Returns lane's element of rho; vec() holds the Bloch vector.
   __device__ static cd lin_invert(const Ctx& c, double& bloch_l) {
-    double acc = 0.0;
-    const double* P = c.pv.PinvT + c.l;
-    const double* fr = c.freq();
-#pragma unroll 8
-    for (int m = 0; m < c.M; ++m) acc += P[(size_t)m * D] * fr[m];
-    bloch_l = acc / d;
+    // bloch_k = sum_m Pinv[k][m] f_m / d, lane = k
+    bloch_l = dot_strided<16>(c.pv.PinvT, D, (unsigned)c.l, c.freq(), c.M) / d;
     c.vec()[c.l] = bloch_l;
     wave_sync();
     cd r = matrix_of(c, c.vec());
@@ -214,108 +268,121 @@ struct Small {
     return r;
   }
 
-  __device__ __forceinline__ static int partner(int i, int r) {
-    if (d == 2) return 1 - i;
-    if (i == d - 1) return r;
-    if (i == r) return d - 1;
-    int p = 2 * r - i;
-    p %= (d - 1);
-    if (p < 0) p += d - 1;
-    return p;
+  // Unitary 2x2 rotation J = [[c, w], [-conj(w), c]] that (nearly) annihilates a_pq of
+  // [[app, apq], [conj(apq), aqq]]: with delta = (aqq - app)/2 and
+  // u = t/|apq| = sign(delta) / (|delta| + sqrt(delta^2 + |apq|^2)):  c = 1/sqrt(1 + u^2 |apq|^2),
+  // w = s e^{i phi} = c u apq.  Only c has to be accurate (it makes J unitary for whatever u is
+  // used); u comes from hardware seeds with one Newton step each (~1e-13): the rotated a_pq is
+  // then kept as computed instead of being set to zero, so an inexact angle costs convergence
+  // speed (nothing measurable), never accuracy.
+  __device__ __forceinline__ static void rotation(double app, double aqq, cd apq, double& cs, cd& w) {
+    const double ab2 = apq.re * apq.re + apq.im * apq.im;
+    cs = 1.0;
+    w = cd{0.0, 0.0};
+    if (ab2 > 1e-300) {
+      const double dl = 0.5 * (aqq - app);
+      const double x = fma(dl, dl, ab2);
+      double y = __builtin_amdgcn_rsq(x);
+      y = fma(y * fma(-x * y, y, 1.0), 0.5, y);
+      const double den = fabs(dl) + x * y;  // |delta| + sqrt(delta^2 + |apq|^2)
+      double z = __builtin_amdgcn_rcp(den);
+      z = fma(z, fma(-den, z, 1.0), z);
+      const double u = copysign(z, dl);
+      cs = fast_rsqrt(fma(u * u, ab2, 1.0));
+      const double cu = cs * u;
+      w = cd{cu * apq.re, cu * apq.im};
+    }
   }
 
   // ---- a7: eigenvalue clip + trace renormalisation by a parallel-order cyclic Jacobi.
   // In: lane's element of a Hermitian matrix.  Out: lane's element of U max(v, eps) U^dagger / Tr.
+  // Round r = 1 .. d-1 rotates the d/2 disjoint pairs (k, k ^ r): every pair once per sweep, and
+  // lane (i, j)'s partners are lanes l ^ r (column), l ^ (r d) (row) and l ^ (r d + r), so a
+  // round is two shuffle stages -- fetch the 2x2 blocks that define the two rotations this lane
+  // needs, then fetch the three partner elements and apply A' = J^dagger A J in one go.  LDS is
+  // touched only for the final rebuild.
   __device__ static cd psd_project(const Ctx& c, cd a, double eps) {
-    cd* A = c.A();
-    cd* Tm = c.Bm();
-    cd* Vc = c.V0();
-    cd* Vn = c.V1();
-    double* rot = c.rot();
     const int i = c.i, j = c.j;
     cd v{i == j ? 1.0 : 0.0, 0.0};
     if (i == j) a.im = 0.0;
-    A[c.l] = a;
-    Vc[c.l] = v;
-    wave_sync();
-    for (int sweep = 0; sweep < 16; ++sweep) {
-      const double n2 = a.re * a.re + a.im * a.im;
-      const double off = gsum<G>(i != j ? n2 : 0.0);
-      const double nrm = gsum<G>(n2);
-      const bool done = !(off > 1e-30 * nrm);
-      if (__all(done)) break;
+    const double nrm = gsum<G>(a.re * a.re + a.im * a.im);  // Frobenius norm: invariant
+    for (int sweep = 0; sweep < 20; ++sweep) {
+      const double off = gsum<G>(i != j ? a.re * a.re + a.im * a.im : 0.0);
+      if (__all(!(off > 1e-30 * nrm))) break;
 #pragma unroll 1
-      for (int r = 0; r < (d == 2 ? 1 : d - 1); ++r) {
-        // rotation for pair t = l % (d/2) of this round
+      for (int r = 1; r < d; ++r) {
+        const int pj = j ^ r, pi = i ^ r;
+        // rotation of the column pair {j, pj} and of the row pair {i, pi}
+        double cj, ci;
+        cd wj, wi;
         {
-          const int t = c.l % (d / 2);
-          int pa, pb;
-          if (t == 0) {
-            pa = d - 1;
-            pb = (d == 2) ? 0 : r;
-          } else {
-            pa = (r + t) % (d - 1);
-            pb = (r - t + (d - 1)) % (d - 1);
-          }
-          const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
-          const double app = A[p * d + p].re, aqq = A[q * d + q].re;
-          const cd apq = A[p * d + q];
-          const double ab = hypot(apq.re, apq.im);
-          double cs = 1.0, sn = 0.0, ere = 1.0, eim = 0.0;
-          if (ab > 1e-290) {
-            const double tau = (aqq - app) / (2.0 * ab);
-            const double tt = copysign(1.0, tau) / (fabs(tau) + hypot(1.0, tau));
-            cs = 1.0 / sqrt(1.0 + tt * tt);
-            sn = tt * cs;
-            ere = apq.re / ab;
-            eim = apq.im / ab;
-          }
-          if (c.l < d / 2) {
-            // off[x] = J[partner(x)][x]:  J_qp = -s e^{-i phi} (x = p),  J_pq = s e^{i phi} (x = q)
-            rot[p] = cs;
-            rot[q] = cs;
-            rot[d + p] = -sn * ere;
-            rot[2 * d + p] = sn * eim;
-            rot[d + q] = sn * ere;
-            rot[2 * d + q] = sn * eim;
-          }
+          const int p = j < pj ? j : pj, q = j < pj ? pj : j;
+          const double app = __shfl(a.re, p * d + p, G), aqq = __shfl(a.re, q * d + q, G);
+          const cd apq{__shfl(a.re, p * d + q, G), __shfl(a.im, p * d + q, G)};
+          rotation(app, aqq, apq, cj, wj);
+          if (j < pj) wj = cd{-wj.re, wj.im};  // J[pj][j]: -conj(w) when j is the lower index, w otherwise
         }
-        wave_sync();
-        const int pj = partner(j, r), pi = partner(i, r);
-        const double cj = rot[j], ci = rot[i];
-        const cd oj{rot[d + j], rot[2 * d + j]};
-        const cd oi{rot[d + i], rot[2 * d + i]};
-        // column step: T = A J, V' = V J
-        const cd t_ij = cadd(cscale(a, cj), cmul(A[i * d + pj], oj));
-        v = cadd(cscale(v, cj), cmul(Vc[i * d + pj], oj));
-        Tm[c.l] = t_ij;
-        Vn[c.l] = v;
-        wave_sync();
-        // row step: A' = J^dagger T
-        cd an = cadd(cscale(t_ij, ci), cmulc(Tm[pi * d + j], oi));  // ci T_ij + conj(oi) T[pi][j]
-        if (j == pi) an = cd{0.0, 0.0};
-        if (i == j) an.im = 0.0;
-        a = an;
-        A[c.l] = a;
-        cd* sw = Vc;
-        Vc = Vn;
-        Vn = sw;
-        wave_sync();
+        {
+          const int p = i < pi ? i : pi, q = i < pi ? pi : i;
+          const double app = __shfl(a.re, p * d + p, G), aqq = __shfl(a.re, q * d + q, G);
+          const cd apq{__shfl(a.re, p * d + q, G), __shfl(a.im, p * d + q, G)};
+          rotation(app, aqq, apq, ci, wi);
+          if (i < pi) wi = cd{-wi.re, wi.im};
+        }
+        // A'_ij = ci (a_ij cj + a_i,pj wj) + conj(wi) (a_pi,j cj + a_pi,pj wj) ;  V' = V J
+        const cd a_c{__shfl_xor(a.re, r, 64), __shfl_xor(a.im, r, 64)};                  // a[i][pj]
+        const cd a_r{__shfl_xor(a.re, r * d, 64), __shfl_xor(a.im, r * d, 64)};          // a[pi][j]
+        const cd a_x{__shfl_xor(a.re, r * d + r, 64), __shfl_xor(a.im, r * d + r, 64)};  // a[pi][pj]
+        const cd v_c{__shfl_xor(v.re, r, 64), __shfl_xor(v.im, r, 64)};
+        const cd t0 = cadd(cscale(a, cj), cmul(a_c, wj));
+        const cd t1 = cadd(cscale(a_r, cj), cmul(a_x, wj));
+        a = cadd(cscale(t0, ci), cmulc(t1, wi));
+        v = cadd(cscale(v, cj), cmul(v_c, wj));
+        if (i == j) a.im = 0.0;
       }
     }
     // rebuild with clipped eigenvalues: R_ij = sum_k V_ik max(lam_k, eps) conj(V_jk)
+    cd* Vm = c.V0();
+    double* lam = c.rot();
+    Vm[c.l] = v;
+    if (i == j) lam[i] = a.re;
+    wave_sync();
     cd rr{0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < d; ++k) {
-      const double lam = A[k * d + k].re;
-      const double lc = lam > eps ? lam : eps;  // np.maximum(eps, v)
-      const cd p = cmulc(Vc[i * d + k], Vc[j * d + k]);
+      const double lc = lam[k] > eps ? lam[k] : eps;  // np.maximum(eps, v)
+      const cd p = cmulc(Vm[i * d + k], Vm[j * d + k]);
       rr.re += lc * p.re;
       rr.im += lc * p.im;
     }
     const double tr = gsum<G>(i == j ? rr.re : 0.0);
     wave_sync();
     return cd{rr.re / tr, rr.im / tr};
+  }
+
+  // a7 with the positive-definite shortcut: when the Hermitian input is numerically positive
+  // definite (its Cholesky factorisation runs through) no eigenvalue is below the clip, so
+  // U max(v, 1e-15) U^dagger is the input itself (to rounding) and only the trace division is left.
+  // Returns the projected element; if `xl` is non-null also the Cholesky parameter of the result.
+  __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out) {
+    int ok;
+    double x = cholesky_param(c, r, ok);
+    const double tr = gsum<G>(c.i == c.j ? r.re : 0.0);
+    cd out{r.re / tr, r.im / tr};
+    x = x / sqrt(tr);  // L of r/tr
+    if (!__all(ok)) {
+      const cd proj = psd_project(c, r, 1e-15);  // whole wave runs it; PD trials keep their shortcut
+      int ok2;
+      const double x2 = xl ? cholesky_param(c, proj, ok2) : 0.0;
+      if (!ok) {
+        out = proj;
+        x = x2;
+        ok = xl ? ok2 : 1;
+      }
+    }
+    if (xl) *xl = x;
+    if (ok_out) *ok_out = ok;
+    return out;
   }
 
   // ---- a8: lower Cholesky factor of the matrix whose element this lane holds.
@@ -389,14 +456,12 @@ struct Small {
     double fpart = 0.0;
     const double* fr = c.freq();
     double* rb = c.rbuf();
+    const unsigned lo = (unsigned)c.l;
     for (int m0 = 0; m0 < c.M; m0 += G) {
-      const int mm = m0 + c.l;
-      if (mm < c.M) {
-        const double* col = c.pv.AwT + mm;
-        double acc = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < D; ++k) acc += col[(size_t)k * c.M] * vec[k];
-        const double pe = acc * d + 1e-10;
+      const unsigned mm = (unsigned)m0 + lo;
+      if ((int)mm < c.M) {
+        // [D][M] layout: uniform row base k*M, per-lane column mm
+        const double pe = dot_strided<(D < 16 ? D : 16)>(c.pv.AwT, (size_t)c.M, mm, vec, D) * d + 1e-10;
         fpart += fr[mm] * log(pe);
         rb[mm] = fr[mm] / pe;
       }
@@ -404,12 +469,7 @@ struct Small {
     f = -gsum<G>(fpart);
     wave_sync();
     // w = A'^T r ;  G = -sum_k w_k P_k ;  Gt = (G - Tr(G rho) I) / t
-    double wl = 0.0;
-    {
-      const double* row = c.pv.Aw + c.l;
-#pragma unroll 8
-      for (int mm = 0; mm < c.M; ++mm) wl += row[(size_t)mm * D] * rb[mm];
-    }
+    const double wl = dot_strided<16>(c.pv.Aw, D, lo, rb, c.M);
     const double tr_g_rho = -(double)d * gsum<G>(wl * bl);
     vec[c.l] = wl;
     wave_sync();
@@ -452,7 +512,7 @@ __global__ void __launch_bounds__(64) k_lin_batch(PovmView pv, const int64_t* __
   S::load_freq(c, counts + (size_t)bb * pv.M);
   double bl;
   cd r = S::lin_invert(c, bl);
-  if (physical) r = S::psd_project(c, r, 1e-15);
+  if (physical) r = S::make_feasible(c, r, nullptr, nullptr);
   if (live) {
     double* out = rho + ((size_t)b * S::D + c.l) * 2;
     out[0] = r.re;
@@ -526,12 +586,18 @@ __global__ void __launch_bounds__(64) k_nll_batch(PovmView pv, const double* __r
   }
 }
 
-// a10: the whole MLE of a trial in one launch.
+// a10, part 1: starting point (state.py:205-212), Cholesky parametrisation and the first
+// (value, gradient) evaluation.  Trials whose gradient already meets gtol -- every full-rank
+// high-shot trial, where BFGS exits at iteration 0 -- are finished here; the
+// rest hand x0, g0, f0 to k_mle_bfgs.  Keeping the D x D inverse Hessian out of this kernel
+// keeps it at ~80 VGPRs (6 waves/SIMD) instead of 256.
 template <int NQ>
-__global__ void __launch_bounds__(64) k_mle_batch(PovmView pv, const int64_t* __restrict__ counts, int B, int init,
+__global__ void __launch_bounds__(64) k_mle_start(PovmView pv, const int64_t* __restrict__ counts, int B, int init,
                                                   int max_iter, double gtol, double* __restrict__ rho,
                                                   int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
-                                                  double* __restrict__ fun_out, int32_t* __restrict__ status_out) {
+                                                  double* __restrict__ fun_out, int32_t* __restrict__ status_out,
+                                                  double* __restrict__ ws_x, double* __restrict__ ws_g,
+                                                  double* __restrict__ ws_f, int32_t* __restrict__ ws_active) {
   using S = Small<NQ>;
   constexpr int D = S::D, G = S::G, d = S::d;
   extern __shared__ double smem[];
@@ -542,50 +608,90 @@ __global__ void __launch_bounds__(64) k_mle_batch(PovmView pv, const int64_t* __
   const bool live = b < B;
   const int bb = live ? b : B - 1;
   S::load_freq(c, counts + (size_t)bb * pv.M);
-
-  // ---- starting point (state.py:205-212)
-  cd r0;
+  int ok;
+  double xk;
   if (init == 0) {
     double bl;
-    r0 = S::lin_invert(c, bl);
-    r0 = S::psd_project(c, r0, 1e-15);
+    const cd lin = S::lin_invert(c, bl);
+    S::make_feasible(c, lin, &xk, &ok);  // physical 'lin' estimate, already Cholesky-parametrised
   } else {
-    r0 = cd{c.i == c.j ? 1.0 / d : 0.0, 0.0};
+    xk = S::cholesky_param(c, cd{c.i == c.j ? 1.0 / d : 0.0, 0.0}, ok);
   }
-  int ok;
-  double xk = S::cholesky_param(c, r0, ok);
+  double fk, gk;
+  S::nll_grad(c, xk, fk, gk);
+  const double gnorm = gmax<G>(fabs(gk));
+  const bool iterate = ok && (gnorm > gtol) && (0 < max_iter);
+  int status = 0;
+  if (!ok) status = 1;
+  else if (!iterate) {
+    const double xn = gmax<G>(fabs(xk));
+    if (0 >= max_iter) status = 3;
+    else if (gnorm != gnorm || fk != fk || xn != xn) status = 4;
+  }
+  double tr;
+  const cd m = S::build_llh(c, xk, tr);
+  if (live) {
+    double* out = rho + ((size_t)b * D + c.l) * 2;
+    out[0] = m.re / tr;
+    out[1] = m.im / tr;
+    ws_x[(size_t)b * D + c.l] = xk;
+    ws_g[(size_t)b * D + c.l] = gk;
+    if (c.l == 0) {
+      ws_f[b] = fk;
+      ws_active[b] = iterate ? 1 : 0;
+      if (nit_out) nit_out[b] = 0;
+      if (nfev_out) nfev_out[b] = ok ? 1 : 0;
+      if (fun_out) fun_out[b] = fk;
+      if (status_out) status_out[b] = status;
+    }
+  }
+}
 
-  // ---- BFGS (scipy _minimize_bfgs): one (value, gradient) evaluation per loop pass
+// a10, part 2: the BFGS iterations (scipy _minimize_bfgs) for the trials k_mle_start left open.
+// One (value, gradient) evaluation per loop pass; the line search is the state machine of
+// qt_linesearch.h; the inverse Hessian is one row per lane in registers.
+template <int NQ>
+__global__ void __launch_bounds__(64) k_mle_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B, int max_iter,
+                                                 double gtol, double* __restrict__ rho, int32_t* __restrict__ nit_out,
+                                                 int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,
+                                                 int32_t* __restrict__ status_out, const double* __restrict__ ws_x,
+                                                 const double* __restrict__ ws_g, const double* __restrict__ ws_f,
+                                                 const int32_t* __restrict__ ws_active) {
+  using S = Small<NQ>;
+  constexpr int D = S::D, G = S::G;
+  const int tib0 = (threadIdx.x & 63) / G;
+  const int b = blockIdx.x * S::TPW + tib0;
+  const bool live = b < B;
+  bool active = live && ws_active[b] != 0;
+  if (!__any(active)) return;  // nothing left to iterate in this wave
+  extern __shared__ double smem[];
+  typename S::Ctx c;
+  S::make_ctx(c, smem, pv);
+  const int bb = live ? b : B - 1;
+  S::load_freq(c, counts + (size_t)bb * pv.M);
+
+  double xk = ws_x[(size_t)bb * D + c.l];
+  double gk = ws_g[(size_t)bb * D + c.l];
+  double fk = ws_f[bb];
   double H[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) H[k] = (k == c.l) ? 1.0 : 0.0;
-  double gk = 0.0, pk = 0.0, fk = 0.0, old_old = 0.0, stp = 0.0;
-  int kiter = 0, nfev = 0, status = ok ? 0 : 1;
-  bool active = ok != 0;
-  int phase = 0;  // 0: first evaluation at x0, 1: inside a line search
+  double old_old = fk + sqrt(gsum<G>(gk * gk)) / 2.0;
+  double pk = -gk, stp = 0.0;  // H0 = I
+  int kiter = 0, nfev = 1, status = 0;
   LineSearch ls;
   double* vec = c.vec();
+  ls.start(fk, old_old, gsum<G>(gk * pk), &stp);
   const int eval_cap = (max_iter + 2) * 130;  // hard stop: every wave leaves the loop
 
   while (__any(active)) {
-    const double xt = (phase == 0) ? xk : xk + stp * pk;
     double ft, gt;
-    S::nll_grad(c, xt, ft, gt);  // executed by the whole wave; finished trials idle through it
-    bool new_direction = false;
+    S::nll_grad(c, xk + stp * pk, ft, gt);  // executed by the whole wave; finished trials idle through it
     if (active && ++nfev > eval_cap) {
       status = 2;
       active = false;
     }
-    if (!active) {
-      // nothing: this trial has finished
-    } else if (phase == 0) {
-      fk = ft;
-      gk = gt;
-      old_old = fk + sqrt(gsum<G>(gk * gk)) / 2.0;
-      const double gnorm = gmax<G>(fabs(gk));
-      if (!(gnorm > gtol) || !(kiter < max_iter)) active = false;
-      else new_direction = true;
-    } else {
+    if (active) {
       const double dphi = gsum<G>(gt * pk);
       double next = stp;
       const int r = ls.advance(stp, ft, dphi, &next);
@@ -595,7 +701,7 @@ __global__ void __launch_bounds__(64) k_mle_batch(PovmView pv, const int64_t* __
         status = 2;
         active = false;
       } else {
-        // step accepted: x += s, y = g_new - g, BFGS update (scipy _optimize.py, rhok = 1000 if y.s == 0)
+        // step accepted: x += s, y = g_new - g, BFGS update (rhok = 1000 if y.s == 0)
         const double sk = stp * pk;
         const double pnorm2 = gsum<G>(pk * pk);
         xk = xk + sk;
@@ -632,22 +738,20 @@ __global__ void __launch_bounds__(64) k_mle_batch(PovmView pv, const int64_t* __
           for (int k = 0; k < D; ++k)
             H[k] += -rhok * (u * ubuf[D + k] + sk * ubuf[k]) + cc * sk * ubuf[D + k];
           wave_sync();
-          if (!(kiter < max_iter)) active = false;
-          else new_direction = true;
+          if (!(kiter < max_iter)) {
+            active = false;
+          } else {
+            vec[c.l] = gk;
+            wave_sync();
+            double hp = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) hp += H[k] * vec[k];
+            wave_sync();
+            pk = -hp;
+            ls.start(fk, old_old, gsum<G>(gk * pk), &stp);
+          }
         }
       }
-    }
-    if (new_direction) {
-      vec[c.l] = gk;
-      wave_sync();
-      double hp = 0.0;
-#pragma unroll
-      for (int k = 0; k < D; ++k) hp += H[k] * vec[k];
-      wave_sync();
-      pk = -hp;
-      const double derphi0 = gsum<G>(gk * pk);
-      ls.start(fk, old_old, derphi0, &stp);
-      phase = 1;
     }
   }
   if (status == 0) {
@@ -656,11 +760,10 @@ __global__ void __launch_bounds__(64) k_mle_batch(PovmView pv, const int64_t* __
     if (kiter >= max_iter) status = 3;
     else if (gn != gn || fk != fk || xn != xn) status = 4;
   }
-
   // ---- result: L L^dagger / Tr  (state.py:214-215)
   double tr;
   const cd m = S::build_llh(c, xk, tr);
-  if (live) {
+  if (live && ws_active[b] != 0) {
     double* out = rho + ((size_t)b * D + c.l) * 2;
     out[0] = m.re / tr;
     out[1] = m.im / tr;

@@ -71,6 +71,8 @@ struct qt_handle {
   DevBuf A, AT, Aw, AwT, Pinv, PinvT, Ns, aug, info;
   // staging for host-pointer calls
   DevBuf in0, in1, out0, out1, out2, out3, out4, proc_aug;
+  // MLE hand-off between k_mle_start and k_mle_bfgs
+  DevBuf ws_x, ws_g, ws_f, ws_act;
   // process tomography
   qt::ProcessState proc;
   bool proc_set = false;
@@ -215,7 +217,8 @@ void qt_destroy(qt_handle_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->in0, &h->in1,
-                    &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug})
+                    &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug, &h->ws_x, &h->ws_g, &h->ws_f,
+                    &h->ws_act})
     b->release();
   h->proc.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -514,12 +517,20 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
   if (int r = stage_out(h, h->out2, nfev, (size_t)B, flags, &dnfev)) return r;
   if (int r = stage_out(h, h->out3, fun, (size_t)B, flags, &dfun)) return r;
   if (int r = stage_out(h, h->out4, status, (size_t)B, flags, &dst)) return r;
+  HIPCHK(h->ws_x.ensure(nel * sizeof(double)));
+  HIPCHK(h->ws_g.ensure(nel * sizeof(double)));
+  HIPCHK(h->ws_f.ensure((size_t)B * sizeof(double)));
+  HIPCHK(h->ws_act.ensure((size_t)B * sizeof(int32_t)));
+  double *wx = h->ws_x.as<double>(), *wg = h->ws_g.as<double>(), *wf = h->ws_f.as<double>();
+  int32_t* wact = h->ws_act.as<int32_t>();
   QT_SMALL_DISPATCH(h->nq, {
     const size_t lds = small_lds_bytes<NQ>(h->M);
     if (int r = check_lds(lds)) return r;
     const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
-    hipLaunchKernelGGL(qt::k_mle_batch<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dc, B, init, max_iter, tol,
-                       drho, dnit, dnfev, dfun, dst);
+    hipLaunchKernelGGL(qt::k_mle_start<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dc, B, init, max_iter, tol,
+                       drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact);
+    hipLaunchKernelGGL(qt::k_mle_bfgs<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dc, B, max_iter, tol, drho,
+                       dnit, dnfev, dfun, dst, wx, wg, wf, wact);
   });
   if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;
   if (int r = fetch_out(h, dnit, nit, (size_t)B, flags)) return r;

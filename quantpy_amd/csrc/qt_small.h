@@ -2,14 +2,20 @@
 //
 // Mapping: one trial is owned by a group of G = D lanes of a 64-wide wavefront (64/G trials per
 // wave; at n = 3 one trial per wave).  Lane l of a group plays three roles at once:
-//   - Bloch / parameter index k = l  (vectors b, w, x, g, p_k of length D live one element/lane),
+//   - Bloch / parameter index k = l  (vectors b, w, x, g of length D live one element per lane),
 //   - matrix element (i, j) = (l / d, l % d) of every d x d complex matrix (rho, L, G, V),
 //   - row m = c*G + l of the M-row POVM contraction, chunk by chunk.
-// Cross-lane traffic goes through a per-trial LDS scratch (broadcast reads) and xor-butterfly
-// shuffles for reductions; a workgroup is exactly one wave, so LDS hand-offs need only the
-// wave-level fence in wave_sync().  The BFGS inverse Hessian (D x D f64) lives in registers,
-// one row per lane (128 VGPRs at n = 3), so nothing but the read-only operands (A', A'^T,
-// left inverse: 111 KB each at n = 3, L2 resident) and the counts / rho of the trial touch HBM.
+// A workgroup is WPB = 4 waves, one per SIMD of a CU.  The waves share ONE read-only LDS image of
+// the current (M x D) operand (left inverse for 'lin', then the weighted POVM A' for the NLL),
+// row-padded to D + 1 doubles so that both access directions -- lane = column (A'^T r, A^+ f) and
+// lane = row (A' b) -- are bank-conflict free.  Measured motivation (profiles/round1_v1_*): with
+// every wave streaming its own 111 KB of A' from L2 per evaluation the batch pulled 14-22 TB/s out
+// of L2 and each wave, alone on its SIMD, sat on L2 latency; from LDS the operand is read at LDS
+// rate and HBM/L2 see it once per workgroup.  After the cooperative image load the waves run
+// independently (wave-level fences only), so trials diverge freely inside BFGS.
+// Per-trial scratch (rho, L, V, b, r, f: ~7 KB) also lives in LDS; the BFGS inverse Hessian
+// (D x D f64) lives in registers, one row per lane.  POVMs too large for the image (M (D+1) 8 B
+// + scratch > 160 KB) take the ALDS = false instantiation, which streams the operand from L2.
 //
 // Reference semantics implemented (paths into /root/reference/quantpy):
 //   lin:  tomography/state.py:191-202, PSD clip :267-273
@@ -41,25 +47,47 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// ---- group reductions on the DPP network (no LDS round trips) ---------------------------------
+// A butterfly inside rows of 16 lanes (quad_perm, row_half_mirror, row_mirror) and, for G = 64,
+// four v_readlane across the rows.  Every lane of a group ends with the same bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }  // NaN wins
+
 template <int G>
 __device__ __forceinline__ double gsum(double v) {
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v += dpp_f64<0xB1>(v);                 // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);                 // quad_perm [2,3,0,1]
+  if (G >= 8) v += dpp_f64<0x141>(v);    // row_half_mirror
+  if (G >= 16) v += dpp_f64<0x140>(v);   // row_mirror
+  if (G == 64) v = (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
   return v;
 }
 template <int G>
 __device__ __forceinline__ double gmax(double v) {
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) {
-    double o = __shfl_xor(v, m, 64);
-    v = (o > v || o != o) ? o : v;  // NaN wins, like np.max
-  }
+  v = nanmax(v, dpp_f64<0xB1>(v));
+  v = nanmax(v, dpp_f64<0x4E>(v));
+  if (G >= 8) v = nanmax(v, dpp_f64<0x141>(v));
+  if (G >= 16) v = nanmax(v, dpp_f64<0x140>(v));
+  if (G == 64)
+    v = nanmax(nanmax(readlane_f64(v, 0), readlane_f64(v, 16)), nanmax(readlane_f64(v, 32), readlane_f64(v, 48)));
   return v;
 }
 
-// 1/sqrt(x) and 1/x for normal-range positive x: hardware seed (v_rsq_f64 / v_rcp_f64) plus two
-// Newton steps -- ~8 dependent FP64 instructions instead of the ~25 of a correctly rounded
-// sqrt-then-divide, accurate to ~1 ulp, which is all a Jacobi rotation needs to stay unitary.
+// 1/sqrt(x) for normal-range positive x: hardware seed (v_rsq_f64) plus two Newton steps -- ~8
+// dependent FP64 instructions instead of the ~25 of a correctly rounded sqrt-then-divide,
+// accurate to ~1 ulp, which is all a Jacobi rotation / Cholesky pivot needs.
 __device__ __forceinline__ double fast_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
   double e = fma(-x * y, y, 1.0);
@@ -67,20 +95,11 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   e = fma(-x * y, y, 1.0);
   return fma(y * e, 0.5, y);
 }
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
-  return fma(y, e, y);
-}
 
-// sum_m base[m * stride + lane_off] * lds_vec[m], m < n: the matrix-vector products of the hot path.
-// `base`/`stride` are wave-uniform (scalar row base), `lane_off` is the lane's column.  The loads
-// of a block of UNR rows are issued back to back before any of them is consumed (the
-// sched_group_barriers pin that order: hipcc otherwise interleaves load / wait / FMA pairs and the
-// wave, alone on its SIMD, eats one L2 latency per pair), and four accumulators keep the FP64
-// FMAs from forming a single dependency chain.
+// sum_m base[m * stride + lane_off] * lds_vec[m], m < n, operand streamed from global memory (L2):
+// the loads of a block of UNR rows are issued back to back before any is consumed (the
+// sched_group_barriers pin that order; hipcc otherwise interleaves load / wait / FMA pairs), and
+// four accumulators keep the FP64 FMAs from forming a single dependency chain.
 template <int UNR>
 __device__ __forceinline__ void dot_block(const double* __restrict__ base, size_t stride, unsigned lane_off,
                                           const double* lds_vec, int m, double (&acc)[4]) {
@@ -89,17 +108,16 @@ __device__ __forceinline__ void dot_block(const double* __restrict__ base, size_
   for (int u = 0; u < UNR; ++u) av[u] = base[(size_t)(m + u) * stride + lane_off];
 #pragma unroll
   for (int u = 0; u < UNR; ++u) acc[u & 3] = fma(av[u], lds_vec[m + u], acc[u & 3]);
-  __builtin_amdgcn_sched_group_barrier(0x020, UNR, 0);  // all VMEM reads of the block first,
+  __builtin_amdgcn_sched_group_barrier(0x020, UNR, 0);
 #pragma unroll
-  for (int u = 0; u < UNR; u += 4) {                    // then LDS broadcast reads feeding FMAs
+  for (int u = 0; u < UNR; u += 4) {
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
   }
 }
-
 template <int UNR>
-__device__ __forceinline__ double dot_strided(const double* __restrict__ base, size_t stride, unsigned lane_off,
-                                              const double* lds_vec, int n) {
+__device__ __forceinline__ double dot_global(const double* __restrict__ base, size_t stride, unsigned lane_off,
+                                             const double* lds_vec, int n) {
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   int m = 0;
   for (; m + UNR <= n; m += UNR) dot_block<UNR>(base, stride, lane_off, lds_vec, m, acc);
@@ -114,6 +132,21 @@ __device__ __forceinline__ double dot_strided(const double* __restrict__ base, s
   for (; m < n; ++m) acc[0] = fma(base[(size_t)m * stride + lane_off], lds_vec[m], acc[0]);
   return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
+// The same product with the operand in the LDS image: img[m * stride + lane_off].
+__device__ __forceinline__ double dot_lds(const double* img, int stride, int lane_off, const double* lds_vec, int n) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const double* p = img + lane_off;
+  int m = 0;
+#pragma unroll 4
+  for (; m + 4 <= n; m += 4) {
+    a0 = fma(p[(m + 0) * stride], lds_vec[m + 0], a0);
+    a1 = fma(p[(m + 1) * stride], lds_vec[m + 1], a1);
+    a2 = fma(p[(m + 2) * stride], lds_vec[m + 2], a2);
+    a3 = fma(p[(m + 3) * stride], lds_vec[m + 3], a3);
+  }
+  for (; m < n; ++m) a0 = fma(p[m * stride], lds_vec[m], a0);
+  return (a0 + a1) + (a2 + a3);
+}
 
 struct PovmView {
   const double* Aw;    // [M][D]  shot-weighted A'
@@ -122,30 +155,38 @@ struct PovmView {
   int M;
 };
 
-template <int NQ>
+template <int NQ, bool ALDS>
 struct Small {
   static constexpr int d = 1 << NQ;
   static constexpr int D = d * d;
   static constexpr int G = D;
-  static constexpr int TPW = 64 / G;
+  static constexpr int TPW = 64 / G;       // trials per wave
+  static constexpr int WPB = 4;            // waves per workgroup
+  static constexpr int NT = 64 * WPB;      // threads per workgroup
+  static constexpr int TPB = TPW * WPB;    // trials per workgroup
   static constexpr int T = d * (d - 1) / 2;
-  // per-trial LDS layout, in doubles
+  static constexpr int LDA = D + 1;        // row pitch of the LDS operand image
+  // per-trial LDS scratch, in doubles
   static constexpr int oA = 0;             // complex [d][d]
   static constexpr int oB = oA + 2 * D;    // complex [d][d]
-  static constexpr int oV0 = oB + 2 * D;   // complex [d][d]
-  static constexpr int oV1 = oV0 + 2 * D;  // complex [d][d]
-  static constexpr int oVec = oV1 + 2 * D; // [D]
-  static constexpr int oRot = oVec + D;    // [4 d]: c, off.re, off.im, (pad)
-  static constexpr int oM = oRot + 4 * d;  // rbuf[Mp], freq[Mp]
-  __host__ __device__ static int lds_doubles(int M) {
-    int Mp = (M + 1) & ~1;
+  static constexpr int oV = oB + 2 * D;    // complex [d][d]
+  static constexpr int oVec = oV + 2 * D;  // [D]
+  static constexpr int oLam = oVec + D;    // [d] (+ pad to even)
+  static constexpr int oM = oLam + 2 * ((d + 1) / 2);  // rbuf[Mp], freq[Mp]
+  __host__ __device__ static int trial_doubles(int M) {
+    const int Mp = (M + 1) & ~1;
     return oM + 2 * Mp;
+  }
+  __host__ __device__ static int image_doubles(int M) { return ALDS ? ((M * LDA + 1) & ~1) : 0; }
+  __host__ __device__ static size_t lds_bytes(int M) {
+    return ((size_t)image_doubles(M) + (size_t)TPB * trial_doubles(M)) * sizeof(double);
   }
 
   // ---- per-lane context ---------------------------------------------------------------
   struct Ctx {
     int l, i, j;     // lane in group, matrix element
     double* sm;      // this trial's LDS scratch
+    double* img;     // the workgroup's operand image (ALDS)
     int M, Mp;
     PovmView pv;
     // Pauli string k = l:  P_k[r][r ^ xm] = (-i)^ny (-1)^popc(r & zm)
@@ -154,24 +195,32 @@ struct Small {
     int pi, pj, pkind;
     __device__ __forceinline__ cd* A() const { return reinterpret_cast<cd*>(sm + oA); }
     __device__ __forceinline__ cd* Bm() const { return reinterpret_cast<cd*>(sm + oB); }
-    __device__ __forceinline__ cd* V0() const { return reinterpret_cast<cd*>(sm + oV0); }
-    __device__ __forceinline__ cd* V1() const { return reinterpret_cast<cd*>(sm + oV1); }
+    __device__ __forceinline__ cd* V() const { return reinterpret_cast<cd*>(sm + oV); }
     __device__ __forceinline__ double* vec() const { return sm + oVec; }
-    __device__ __forceinline__ double* rot() const { return sm + oRot; }
+    __device__ __forceinline__ double* lam() const { return sm + oLam; }
     __device__ __forceinline__ double* rbuf() const { return sm + oM; }
     __device__ __forceinline__ double* freq() const { return sm + oM + Mp; }
   };
 
+  // Trial handled by this lane's group; *live = false for the padding groups of the last block.
+  __device__ __forceinline__ static int trial_index(int B, bool* live) {
+    const int wave = threadIdx.x >> 6, tib = (threadIdx.x & 63) / G;
+    const int b = (blockIdx.x * WPB + wave) * TPW + tib;
+    *live = b < B;
+    return b;
+  }
+
   __device__ static void make_ctx(Ctx& c, double* smem_block, const PovmView& pv) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     c.l = lane % G;
-    const int tib = lane / G;
+    const int slot = wave * TPW + lane / G;
     c.i = c.l / d;
     c.j = c.l % d;
     c.M = pv.M;
     c.Mp = (pv.M + 1) & ~1;
     c.pv = pv;
-    c.sm = smem_block + tib * lds_doubles(pv.M);
+    c.img = smem_block;
+    c.sm = smem_block + image_doubles(pv.M) + slot * trial_doubles(pv.M);
     int xm = 0, zm = 0, ny = 0;
 #pragma unroll
     for (int b = 0; b < NQ; ++b) {
@@ -200,6 +249,15 @@ struct Small {
     }
   }
 
+  // Cooperative copy of a row-major [M][D] operand into the padded LDS image (whole workgroup).
+  __device__ static void load_image(const Ctx& c, const double* __restrict__ g) {
+    if (!ALDS) return;
+    __syncthreads();  // every wave is done with the previous image
+    const int total = c.M * D;
+    for (int e = threadIdx.x; e < total; e += NT) c.img[(e / D) * LDA + (e % D)] = g[e];
+    __syncthreads();
+  }
+
   // Bloch index of the Pauli string with X-type mask x and Z-type mask z.
   __device__ __forceinline__ static int pauli_index(int x, int z) {
     int k = 0;
@@ -211,7 +269,6 @@ struct Small {
     }
     return k;
   }
-
   // Re[(-i)^ny * s]
   __device__ __forceinline__ static double re_phase(int ny, cd s) {
     return ny == 0 ? s.re : ny == 1 ? s.im : ny == 2 ? -s.re : -s.im;
@@ -257,10 +314,20 @@ struct Small {
     wave_sync();
   }
 
-  // ---- a6: linear inversion.  Returns lane's element of rho; vec() holds the Bloch vector.
+  // sum_m Op[m][lane] * vec[m]   (lane = column)
+  __device__ __forceinline__ static double col_dot(const Ctx& c, const double* g_rowmajor, const double* vec) {
+    if (ALDS) return dot_lds(c.img, LDA, c.l, vec, c.M);
+    return dot_global<16>(g_rowmajor, D, (unsigned)c.l, vec, c.M);
+  }
+  // sum_k Op[row][k] * vec[k]    (lane = row), g_transposed = [D][M]
+  __device__ __forceinline__ static double row_dot(const Ctx& c, const double* g_transposed, int row, const double* vec) {
+    if (ALDS) return dot_lds(c.img + row * LDA, 1, 0, vec, D);
+    return dot_global<(D < 16 ? D : 16)>(g_transposed, (size_t)c.M, (unsigned)row, vec, D);
+  }
+
+  // ---- a6: linear inversion (image = PinvT).  Returns lane's element of rho; vec() = Bloch vector.
   __device__ static cd lin_invert(const Ctx& c, double& bloch_l) {
-    // bloch_k = sum_m Pinv[k][m] f_m / d, lane = k
-    bloch_l = dot_strided<16>(c.pv.PinvT, D, (unsigned)c.l, c.freq(), c.M) / d;
+    bloch_l = col_dot(c, c.pv.PinvT, c.freq()) / d;  // bloch_k = sum_m Pinv[k][m] f_m / d
     c.vec()[c.l] = bloch_l;
     wave_sync();
     cd r = matrix_of(c, c.vec());
@@ -273,8 +340,8 @@ struct Small {
   // u = t/|apq| = sign(delta) / (|delta| + sqrt(delta^2 + |apq|^2)):  c = 1/sqrt(1 + u^2 |apq|^2),
   // w = s e^{i phi} = c u apq.  Only c has to be accurate (it makes J unitary for whatever u is
   // used); u comes from hardware seeds with one Newton step each (~1e-13): the rotated a_pq is
-  // then kept as computed instead of being set to zero, so an inexact angle costs convergence
-  // speed (nothing measurable), never accuracy.
+  // kept as computed instead of being set to zero, so an inexact angle costs convergence speed
+  // (nothing measurable), never accuracy.
   __device__ __forceinline__ static void rotation(double app, double aqq, cd apq, double& cs, cd& w) {
     const double ab2 = apq.re * apq.re + apq.im * apq.im;
     cs = 1.0;
@@ -296,44 +363,42 @@ struct Small {
 
   // ---- a7: eigenvalue clip + trace renormalisation by a parallel-order cyclic Jacobi.
   // In: lane's element of a Hermitian matrix.  Out: lane's element of U max(v, eps) U^dagger / Tr.
-  // Round r = 1 .. d-1 rotates the d/2 disjoint pairs (k, k ^ r): every pair once per sweep, and
-  // lane (i, j)'s partners are lanes l ^ r (column), l ^ (r d) (row) and l ^ (r d + r), so a
-  // round is two shuffle stages -- fetch the 2x2 blocks that define the two rotations this lane
-  // needs, then fetch the three partner elements and apply A' = J^dagger A J in one go.  LDS is
-  // touched only for the final rebuild.
+  // Round r = 1 .. d-1 rotates the d/2 disjoint pairs (k, k ^ r): every pair once per sweep.  A
+  // round is ONE LDS round trip: the lanes publish A and V, then each lane reads the two 2x2
+  // blocks that define the rotations of its column pair {j, j^r} and row pair {i, i^r} together
+  // with its three partner elements, and applies A' = J^dagger A J, V' = V J in registers.
   __device__ static cd psd_project(const Ctx& c, cd a, double eps) {
     const int i = c.i, j = c.j;
+    cd* Ai = c.A();
+    cd* Vi = c.V();
     cd v{i == j ? 1.0 : 0.0, 0.0};
     if (i == j) a.im = 0.0;
     const double nrm = gsum<G>(a.re * a.re + a.im * a.im);  // Frobenius norm: invariant
     for (int sweep = 0; sweep < 20; ++sweep) {
       const double off = gsum<G>(i != j ? a.re * a.re + a.im * a.im : 0.0);
-      if (__all(!(off > 1e-30 * nrm))) break;
+      if (__all(!(off > 1e-28 * nrm))) break;
 #pragma unroll 1
       for (int r = 1; r < d; ++r) {
+        Ai[c.l] = a;
+        Vi[c.l] = v;
+        wave_sync();
         const int pj = j ^ r, pi = i ^ r;
-        // rotation of the column pair {j, pj} and of the row pair {i, pi}
+        const int cp = j < pj ? j : pj, cq = j < pj ? pj : j;  // column pair, ordered
+        const int rp = i < pi ? i : pi, rq = i < pi ? pi : i;  // row pair, ordered
+        const double c_pp = Ai[cp * d + cp].re, c_qq = Ai[cq * d + cq].re;
+        const cd c_pq = Ai[cp * d + cq];
+        const double r_pp = Ai[rp * d + rp].re, r_qq = Ai[rq * d + rq].re;
+        const cd r_pq = Ai[rp * d + rq];
+        const cd a_c = Ai[i * d + pj], a_r = Ai[pi * d + j], a_x = Ai[pi * d + pj];
+        const cd v_c = Vi[i * d + pj];
+        wave_sync();  // all reads of this image are issued before the next round overwrites it
         double cj, ci;
         cd wj, wi;
-        {
-          const int p = j < pj ? j : pj, q = j < pj ? pj : j;
-          const double app = __shfl(a.re, p * d + p, G), aqq = __shfl(a.re, q * d + q, G);
-          const cd apq{__shfl(a.re, p * d + q, G), __shfl(a.im, p * d + q, G)};
-          rotation(app, aqq, apq, cj, wj);
-          if (j < pj) wj = cd{-wj.re, wj.im};  // J[pj][j]: -conj(w) when j is the lower index, w otherwise
-        }
-        {
-          const int p = i < pi ? i : pi, q = i < pi ? pi : i;
-          const double app = __shfl(a.re, p * d + p, G), aqq = __shfl(a.re, q * d + q, G);
-          const cd apq{__shfl(a.re, p * d + q, G), __shfl(a.im, p * d + q, G)};
-          rotation(app, aqq, apq, ci, wi);
-          if (i < pi) wi = cd{-wi.re, wi.im};
-        }
+        rotation(c_pp, c_qq, c_pq, cj, wj);
+        rotation(r_pp, r_qq, r_pq, ci, wi);
+        if (j < pj) wj = cd{-wj.re, wj.im};  // J[pj][j]: -conj(w) if j is the lower index, else w
+        if (i < pi) wi = cd{-wi.re, wi.im};
         // A'_ij = ci (a_ij cj + a_i,pj wj) + conj(wi) (a_pi,j cj + a_pi,pj wj) ;  V' = V J
-        const cd a_c{__shfl_xor(a.re, r, 64), __shfl_xor(a.im, r, 64)};                  // a[i][pj]
-        const cd a_r{__shfl_xor(a.re, r * d, 64), __shfl_xor(a.im, r * d, 64)};          // a[pi][j]
-        const cd a_x{__shfl_xor(a.re, r * d + r, 64), __shfl_xor(a.im, r * d + r, 64)};  // a[pi][pj]
-        const cd v_c{__shfl_xor(v.re, r, 64), __shfl_xor(v.im, r, 64)};
         const cd t0 = cadd(cscale(a, cj), cmul(a_c, wj));
         const cd t1 = cadd(cscale(a_r, cj), cmul(a_x, wj));
         a = cadd(cscale(t0, ci), cmulc(t1, wi));
@@ -342,47 +407,21 @@ struct Small {
       }
     }
     // rebuild with clipped eigenvalues: R_ij = sum_k V_ik max(lam_k, eps) conj(V_jk)
-    cd* Vm = c.V0();
-    double* lam = c.rot();
-    Vm[c.l] = v;
+    double* lam = c.lam();
+    Vi[c.l] = v;
     if (i == j) lam[i] = a.re;
     wave_sync();
     cd rr{0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < d; ++k) {
       const double lc = lam[k] > eps ? lam[k] : eps;  // np.maximum(eps, v)
-      const cd p = cmulc(Vm[i * d + k], Vm[j * d + k]);
+      const cd p = cmulc(Vi[i * d + k], Vi[j * d + k]);
       rr.re += lc * p.re;
       rr.im += lc * p.im;
     }
     const double tr = gsum<G>(i == j ? rr.re : 0.0);
     wave_sync();
     return cd{rr.re / tr, rr.im / tr};
-  }
-
-  // a7 with the positive-definite shortcut: when the Hermitian input is numerically positive
-  // definite (its Cholesky factorisation runs through) no eigenvalue is below the clip, so
-  // U max(v, 1e-15) U^dagger is the input itself (to rounding) and only the trace division is left.
-  // Returns the projected element; if `xl` is non-null also the Cholesky parameter of the result.
-  __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out) {
-    int ok;
-    double x = cholesky_param(c, r, ok);
-    const double tr = gsum<G>(c.i == c.j ? r.re : 0.0);
-    cd out{r.re / tr, r.im / tr};
-    x = x / sqrt(tr);  // L of r/tr
-    if (!__all(ok)) {
-      const cd proj = psd_project(c, r, 1e-15);  // whole wave runs it; PD trials keep their shortcut
-      int ok2;
-      const double x2 = xl ? cholesky_param(c, proj, ok2) : 0.0;
-      if (!ok) {
-        out = proj;
-        x = x2;
-        ok = xl ? ok2 : 1;
-      }
-    }
-    if (xl) *xl = x;
-    if (ok_out) *ok_out = ok;
-    return out;
   }
 
   // ---- a8: lower Cholesky factor of the matrix whose element this lane holds.
@@ -399,10 +438,10 @@ struct Small {
     for (int k = 0; k < d; ++k) {
       const double akk = A[k * d + k].re;
       if (!(akk > 0.0)) ok = 0;
-      const double lkk = sqrt(akk);
+      const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);  // 1 / l_kk
       const cd aik = A[i * d + k], ajk = A[j * d + k];
-      const cd lik{aik.re / lkk, aik.im / lkk}, ljk{ajk.re / lkk, ajk.im / lkk};
-      if (j == k && i >= k) L[c.l] = (i == k) ? cd{lkk, 0.0} : lik;
+      const cd lik{aik.re * rs, aik.im * rs}, ljk{ajk.re * rs, ajk.im * rs};
+      if (j == k && i >= k) L[c.l] = (i == k) ? cd{akk * rs, 0.0} : lik;
       if (i > k && j > k) {
         const cd p = cmulc(lik, ljk);
         a.re -= p.re;
@@ -415,6 +454,31 @@ struct Small {
     const double x = c.pkind == 2 ? e.im : e.re;
     wave_sync();
     return x;
+  }
+
+  // a7 with the positive-definite shortcut: when the Hermitian input is numerically positive
+  // definite (its Cholesky factorisation runs through) no eigenvalue is below the clip, so
+  // U max(v, 1e-15) U^dagger is the input itself (to rounding) and only the trace division is left.
+  // Returns the projected element; if `xl` is non-null also the Cholesky parameter of the result.
+  __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out) {
+    int ok;
+    double x = cholesky_param(c, r, ok);
+    const double tr = gsum<G>(c.i == c.j ? r.re : 0.0);
+    cd out{r.re / tr, r.im / tr};
+    x = x / sqrt(tr);  // L of r/tr
+    if (!__all(ok)) {
+      const cd proj = psd_project(c, r, 1e-15);  // whole wave runs it; PD trials keep their shortcut
+      int ok2 = 1;
+      const double x2 = xl ? cholesky_param(c, proj, ok2) : 0.0;
+      if (!ok) {
+        out = proj;
+        x = x2;
+        ok = ok2;
+      }
+    }
+    if (xl) *xl = x;
+    if (ok_out) *ok_out = ok;
+    return out;
   }
 
   // x (one parameter per lane) -> L in Bm(), returns lane's element of L L^dagger and t = Tr.
@@ -441,7 +505,7 @@ struct Small {
     return m;
   }
 
-  // ---- a9: NLL value and exact gradient at x.  Needs freq[] loaded.  Leaves L in Bm().
+  // ---- a9: NLL value and exact gradient at x (image = Aw).  Needs freq[] loaded.  Leaves L in Bm().
   __device__ static void nll_grad(const Ctx& c, double xl, double& f, double& gl) {
     double tr;
     const cd m = build_llh(c, xl, tr);
@@ -456,12 +520,10 @@ struct Small {
     double fpart = 0.0;
     const double* fr = c.freq();
     double* rb = c.rbuf();
-    const unsigned lo = (unsigned)c.l;
     for (int m0 = 0; m0 < c.M; m0 += G) {
-      const unsigned mm = (unsigned)m0 + lo;
-      if ((int)mm < c.M) {
-        // [D][M] layout: uniform row base k*M, per-lane column mm
-        const double pe = dot_strided<(D < 16 ? D : 16)>(c.pv.AwT, (size_t)c.M, mm, vec, D) * d + 1e-10;
+      const int mm = m0 + c.l;
+      if (mm < c.M) {
+        const double pe = row_dot(c, c.pv.AwT, mm, vec) * d + 1e-10;
         fpart += fr[mm] * log(pe);
         rb[mm] = fr[mm] / pe;
       }
@@ -469,7 +531,7 @@ struct Small {
     f = -gsum<G>(fpart);
     wave_sync();
     // w = A'^T r ;  G = -sum_k w_k P_k ;  Gt = (G - Tr(G rho) I) / t
-    const double wl = dot_strided<16>(c.pv.Aw, D, lo, rb, c.M);
+    const double wl = col_dot(c, c.pv.Aw, rb);
     const double tr_g_rho = -(double)d * gsum<G>(wl * bl);
     vec[c.l] = wl;
     wave_sync();
@@ -493,22 +555,22 @@ struct Small {
 };
 
 // =========================================================================================
-// kernels
+// kernels (workgroup = 4 waves; a wave owns 64/G trials; `live` masks the padding of the last block)
 // =========================================================================================
 
 // a6 + a7
-template <int NQ>
-__global__ void __launch_bounds__(64) k_lin_batch(PovmView pv, const int64_t* __restrict__ counts, int B, int physical,
-                                                  double* __restrict__ rho, double* __restrict__ bloch_out,
-                                                  int32_t* __restrict__ status) {
-  using S = Small<NQ>;
+template <int NQ, bool ALDS>
+__global__ void __launch_bounds__(256) k_lin_batch(PovmView pv, const int64_t* __restrict__ counts, int B, int physical,
+                                                   double* __restrict__ rho, double* __restrict__ bloch_out,
+                                                   int32_t* __restrict__ status) {
+  using S = Small<NQ, ALDS>;
   extern __shared__ double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
-  const int tib = (threadIdx.x & 63) / S::G;
-  const int b = blockIdx.x * S::TPW + tib;
-  const bool live = b < B;
-  const int bb = live ? b : B - 1;  // idle groups recompute the last trial; nothing is stored
+  bool live;
+  const int b = S::trial_index(B, &live);
+  const int bb = live ? b : B - 1;  // padding groups recompute the last trial; nothing is stored
+  S::load_image(c, pv.PinvT);
   S::load_freq(c, counts + (size_t)bb * pv.M);
   double bl;
   cd r = S::lin_invert(c, bl);
@@ -524,15 +586,14 @@ __global__ void __launch_bounds__(64) k_lin_batch(PovmView pv, const int64_t* __
 
 // a8 forward: rho -> x
 template <int NQ>
-__global__ void __launch_bounds__(64) k_chol_param(PovmView pv, const double* __restrict__ rho, int B,
-                                                   double* __restrict__ x, int32_t* __restrict__ status) {
-  using S = Small<NQ>;
+__global__ void __launch_bounds__(256) k_chol_param(PovmView pv, const double* __restrict__ rho, int B,
+                                                    double* __restrict__ x, int32_t* __restrict__ status) {
+  using S = Small<NQ, false>;
   extern __shared__ double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
-  const int tib = (threadIdx.x & 63) / S::G;
-  const int b = blockIdx.x * S::TPW + tib;
-  const bool live = b < B;
+  bool live;
+  const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;
   const double* in = rho + ((size_t)bb * S::D + c.l) * 2;
   int ok;
@@ -545,15 +606,14 @@ __global__ void __launch_bounds__(64) k_chol_param(PovmView pv, const double* __
 
 // a8 backward: x -> L L^dagger
 template <int NQ>
-__global__ void __launch_bounds__(64) k_chol_unparam(PovmView pv, const double* __restrict__ x, int B,
-                                                     double* __restrict__ llh) {
-  using S = Small<NQ>;
+__global__ void __launch_bounds__(256) k_chol_unparam(PovmView pv, const double* __restrict__ x, int B,
+                                                      double* __restrict__ llh) {
+  using S = Small<NQ, false>;
   extern __shared__ double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
-  const int tib = (threadIdx.x & 63) / S::G;
-  const int b = blockIdx.x * S::TPW + tib;
-  const bool live = b < B;
+  bool live;
+  const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;
   double tr;
   const cd m = S::build_llh(c, x[(size_t)bb * S::D + c.l], tr);
@@ -565,18 +625,18 @@ __global__ void __launch_bounds__(64) k_chol_unparam(PovmView pv, const double* 
 }
 
 // a9
-template <int NQ>
-__global__ void __launch_bounds__(64) k_nll_batch(PovmView pv, const double* __restrict__ x,
-                                                  const int64_t* __restrict__ counts, int B, double* __restrict__ f,
-                                                  double* __restrict__ grad) {
-  using S = Small<NQ>;
+template <int NQ, bool ALDS>
+__global__ void __launch_bounds__(256) k_nll_batch(PovmView pv, const double* __restrict__ x,
+                                                   const int64_t* __restrict__ counts, int B, double* __restrict__ f,
+                                                   double* __restrict__ grad) {
+  using S = Small<NQ, ALDS>;
   extern __shared__ double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
-  const int tib = (threadIdx.x & 63) / S::G;
-  const int b = blockIdx.x * S::TPW + tib;
-  const bool live = b < B;
+  bool live;
+  const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;
+  S::load_image(c, pv.Aw);
   S::load_freq(c, counts + (size_t)bb * pv.M);
   double fv, gl;
   S::nll_grad(c, x[(size_t)bb * S::D + c.l], fv, gl);
@@ -590,31 +650,33 @@ __global__ void __launch_bounds__(64) k_nll_batch(PovmView pv, const double* __r
 // (value, gradient) evaluation.  Trials whose gradient already meets gtol -- every full-rank
 // high-shot trial, where BFGS exits at iteration 0 -- are finished here; the
 // rest hand x0, g0, f0 to k_mle_bfgs.  Keeping the D x D inverse Hessian out of this kernel
-// keeps it at ~80 VGPRs (6 waves/SIMD) instead of 256.
-template <int NQ>
-__global__ void __launch_bounds__(64) k_mle_start(PovmView pv, const int64_t* __restrict__ counts, int B, int init,
-                                                  int max_iter, double gtol, double* __restrict__ rho,
-                                                  int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
-                                                  double* __restrict__ fun_out, int32_t* __restrict__ status_out,
-                                                  double* __restrict__ ws_x, double* __restrict__ ws_g,
-                                                  double* __restrict__ ws_f, int32_t* __restrict__ ws_active) {
-  using S = Small<NQ>;
+// keeps its register footprint small.
+template <int NQ, bool ALDS>
+__global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* __restrict__ counts, int B, int init,
+                                                   int max_iter, double gtol, double* __restrict__ rho,
+                                                   int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
+                                                   double* __restrict__ fun_out, int32_t* __restrict__ status_out,
+                                                   double* __restrict__ ws_x, double* __restrict__ ws_g,
+                                                   double* __restrict__ ws_f, int32_t* __restrict__ ws_active) {
+  using S = Small<NQ, ALDS>;
   constexpr int D = S::D, G = S::G, d = S::d;
   extern __shared__ double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
-  const int tib = (threadIdx.x & 63) / G;
-  const int b = blockIdx.x * S::TPW + tib;
-  const bool live = b < B;
+  bool live;
+  const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;
   S::load_freq(c, counts + (size_t)bb * pv.M);
   int ok;
   double xk;
   if (init == 0) {
+    S::load_image(c, pv.PinvT);
     double bl;
     const cd lin = S::lin_invert(c, bl);
+    S::load_image(c, pv.Aw);  // (barrier inside: every wave is past its read of the left inverse)
     S::make_feasible(c, lin, &xk, &ok);  // physical 'lin' estimate, already Cholesky-parametrised
   } else {
+    S::load_image(c, pv.Aw);
     xk = S::cholesky_param(c, cd{c.i == c.j ? 1.0 / d : 0.0, 0.0}, ok);
   }
   double fk, gk;
@@ -650,24 +712,25 @@ __global__ void __launch_bounds__(64) k_mle_start(PovmView pv, const int64_t* __
 // a10, part 2: the BFGS iterations (scipy _minimize_bfgs) for the trials k_mle_start left open.
 // One (value, gradient) evaluation per loop pass; the line search is the state machine of
 // qt_linesearch.h; the inverse Hessian is one row per lane in registers.
-template <int NQ>
-__global__ void __launch_bounds__(64) k_mle_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B, int max_iter,
-                                                 double gtol, double* __restrict__ rho, int32_t* __restrict__ nit_out,
-                                                 int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,
-                                                 int32_t* __restrict__ status_out, const double* __restrict__ ws_x,
-                                                 const double* __restrict__ ws_g, const double* __restrict__ ws_f,
-                                                 const int32_t* __restrict__ ws_active) {
-  using S = Small<NQ>;
+template <int NQ, bool ALDS>
+__global__ void __launch_bounds__(256) k_mle_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B, int max_iter,
+                                                  double gtol, double* __restrict__ rho, int32_t* __restrict__ nit_out,
+                                                  int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,
+                                                  int32_t* __restrict__ status_out, const double* __restrict__ ws_x,
+                                                  const double* __restrict__ ws_g, const double* __restrict__ ws_f,
+                                                  const int32_t* __restrict__ ws_active) {
+  using S = Small<NQ, ALDS>;
   constexpr int D = S::D, G = S::G;
-  const int tib0 = (threadIdx.x & 63) / G;
-  const int b = blockIdx.x * S::TPW + tib0;
-  const bool live = b < B;
-  bool active = live && ws_active[b] != 0;
-  if (!__any(active)) return;  // nothing left to iterate in this wave
+  bool live;
+  const int b = S::trial_index(B, &live);
+  const bool mine = live && ws_active[b] != 0;
+  bool active = mine;
+  if (!__syncthreads_or(active)) return;  // nothing left to iterate in this workgroup
   extern __shared__ double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
   const int bb = live ? b : B - 1;
+  S::load_image(c, pv.Aw);
   S::load_freq(c, counts + (size_t)bb * pv.M);
 
   double xk = ws_x[(size_t)bb * D + c.l];
@@ -684,7 +747,7 @@ __global__ void __launch_bounds__(64) k_mle_bfgs(PovmView pv, const int64_t* __r
   ls.start(fk, old_old, gsum<G>(gk * pk), &stp);
   const int eval_cap = (max_iter + 2) * 130;  // hard stop: every wave leaves the loop
 
-  while (__any(active)) {
+  while (__any(active)) {  // per wave: the waves of a workgroup no longer synchronise
     double ft, gt;
     S::nll_grad(c, xk + stp * pk, ft, gt);  // executed by the whole wave; finished trials idle through it
     if (active && ++nfev > eval_cap) {
@@ -763,7 +826,7 @@ __global__ void __launch_bounds__(64) k_mle_bfgs(PovmView pv, const int64_t* __r
   // ---- result: L L^dagger / Tr  (state.py:214-215)
   double tr;
   const cd m = S::build_llh(c, xk, tr);
-  if (live && ws_active[b] != 0) {
+  if (mine) {
     double* out = rho + ((size_t)b * D + c.l) * 2;
     out[0] = m.re / tr;
     out[1] = m.im / tr;

@@ -140,26 +140,54 @@ int count_bad(const int32_t* status, int B, int flags) {
   return bad;
 }
 
-template <int NQ>
-size_t small_lds_bytes(int M) {
-  return (size_t)qt::Small<NQ>::TPW * qt::Small<NQ>::lds_doubles(M) * sizeof(double);
+constexpr size_t kLdsLimit = 160 * 1024;  // LDS per CU on gfx950; one workgroup may use all of it
+
+// Launch KERNEL<NQ, ALDS> for the handle's n: the LDS-image variant when image + scratch fit in
+// 160 KB, else the variant that streams the operand from L2.  ARGS is the parenthesised argument list.
+template <class K>
+int allow_big_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)bytes);
+  if (e != hipSuccess) return fail(QT_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", bytes, hipGetErrorString(e));
+  return 0;
 }
 
-#define QT_SMALL_DISPATCH(nq, CALL)                                   \
-  switch (nq) {                                                       \
-    case 1: { constexpr int NQ = 1; CALL; } break;                    \
-    case 2: { constexpr int NQ = 2; CALL; } break;                    \
-    case 3: { constexpr int NQ = 3; CALL; } break;                    \
-    default: return fail(QT_ERR_UNSUPPORTED, "estimators support n_qubits 1..3 in this release (got %d)", nq); \
+#define QT_LAUNCH_ONE(KERNEL, NQV, ALDSV, M_, B_, ARGS)                                                   \
+  do {                                                                                                    \
+    using S_ = qt::Small<NQV, ALDSV>;                                                                     \
+    const size_t lds_ = S_::lds_bytes(M_);                                                                \
+    if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for the n<=3 kernels (%zu B of LDS)", lds_); \
+    if (int r_ = allow_big_lds(KERNEL<NQV, ALDSV>, lds_)) return r_;                                      \
+    const int grid_ = ((B_) + S_::TPB - 1) / S_::TPB;                                                     \
+    hipLaunchKernelGGL((KERNEL<NQV, ALDSV>), dim3(grid_), dim3(S_::NT), lds_, h->stream, QT_UNPACK ARGS); \
+  } while (0)
+#define QT_UNPACK(...) __VA_ARGS__
+#define QT_LAUNCH_N(KERNEL, NQV, M_, B_, ARGS)                          \
+  do {                                                                  \
+    if (qt::Small<NQV, true>::lds_bytes(M_) <= kLdsLimit)               \
+      QT_LAUNCH_ONE(KERNEL, NQV, true, M_, B_, ARGS);                   \
+    else                                                                \
+      QT_LAUNCH_ONE(KERNEL, NQV, false, M_, B_, ARGS);                  \
+  } while (0)
+#define QT_LAUNCH_SMALL(KERNEL, M_, B_, ARGS)                                                               \
+  switch (h->nq) {                                                                                          \
+    case 1: QT_LAUNCH_N(KERNEL, 1, M_, B_, ARGS); break;                                                    \
+    case 2: QT_LAUNCH_N(KERNEL, 2, M_, B_, ARGS); break;                                                    \
+    case 3: QT_LAUNCH_N(KERNEL, 3, M_, B_, ARGS); break;                                                    \
+    default: return fail(QT_ERR_UNSUPPORTED, "estimators support n_qubits 1..3 in this release (got %d)", h->nq); \
+  }
+// kernels without an operand image (Cholesky parametrisation)
+#define QT_LAUNCH_SMALL_NOIMG(KERNEL, B_, ARGS)                                                             \
+  switch (h->nq) {                                                                                          \
+    case 1: { using S_ = qt::Small<1, false>; hipLaunchKernelGGL((KERNEL<1>), dim3(((B_) + S_::TPB - 1) / S_::TPB), dim3(S_::NT), S_::lds_bytes(0), h->stream, QT_UNPACK ARGS); } break; \
+    case 2: { using S_ = qt::Small<2, false>; hipLaunchKernelGGL((KERNEL<2>), dim3(((B_) + S_::TPB - 1) / S_::TPB), dim3(S_::NT), S_::lds_bytes(0), h->stream, QT_UNPACK ARGS); } break; \
+    case 3: { using S_ = qt::Small<3, false>; hipLaunchKernelGGL((KERNEL<3>), dim3(((B_) + S_::TPB - 1) / S_::TPB), dim3(S_::NT), S_::lds_bytes(0), h->stream, QT_UNPACK ARGS); } break; \
+    default: return fail(QT_ERR_UNSUPPORTED, "estimators support n_qubits 1..3 in this release (got %d)", h->nq); \
   }
 
 int need_povm(qt_handle_t* h) {
   if (!h->povm_set) return fail(QT_ERR_STATE, "qt_set_povm has not been called on this handle");
-  return 0;
-}
-
-int check_lds(size_t bytes) {
-  if (bytes > 64 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the LDS-resident kernels (%zu bytes of LDS)", bytes);
   return 0;
 }
 
@@ -419,13 +447,7 @@ int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, dou
   if (int r = stage_out(h, h->out0, rho, nel * 2, flags, &drho)) return r;
   if (int r = stage_out(h, h->out1, bloch_out, nel, flags, &dbl)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
-  QT_SMALL_DISPATCH(h->nq, {
-    const size_t lds = small_lds_bytes<NQ>(h->M);
-    if (int r = check_lds(lds)) return r;
-    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
-    hipLaunchKernelGGL(qt::k_lin_batch<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dc, B, physical, drho, dbl,
-                       dst);
-  });
+  QT_LAUNCH_SMALL(qt::k_lin_batch, h->M, B, (h->view(), dc, B, physical, drho, dbl, dst));
   if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;
   if (int r = fetch_out(h, dbl, bloch_out, nel, flags)) return r;
   if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
@@ -445,11 +467,7 @@ int qt_chol_param(qt_handle_t* h, const double* rho, int B, double* x, int32_t* 
   if (int r = stage_out(h, h->out0, x, nel, flags, &dx)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
   qt::PovmView pv{nullptr, nullptr, nullptr, 0};
-  QT_SMALL_DISPATCH(h->nq, {
-    const size_t lds = small_lds_bytes<NQ>(0);
-    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
-    hipLaunchKernelGGL(qt::k_chol_param<NQ>, dim3(grid), dim3(64), lds, h->stream, pv, din, B, dx, dst);
-  });
+  QT_LAUNCH_SMALL_NOIMG(qt::k_chol_param, B, (pv, din, B, dx, dst));
   if (int r = fetch_out(h, dx, x, nel, flags)) return r;
   if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
   if (int r = finish(h, flags)) return r;
@@ -466,11 +484,7 @@ int qt_chol_unparam(qt_handle_t* h, const double* x, int B, double* LLh, int fla
   if (int r = stage_in(h, h->in0, x, nel, flags, &din)) return r;
   if (int r = stage_out(h, h->out0, LLh, nel * 2, flags, &dout)) return r;
   qt::PovmView pv{nullptr, nullptr, nullptr, 0};
-  QT_SMALL_DISPATCH(h->nq, {
-    const size_t lds = small_lds_bytes<NQ>(0);
-    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
-    hipLaunchKernelGGL(qt::k_chol_unparam<NQ>, dim3(grid), dim3(64), lds, h->stream, pv, din, B, dout);
-  });
+  QT_LAUNCH_SMALL_NOIMG(qt::k_chol_unparam, B, (pv, din, B, dout));
   if (int r = fetch_out(h, dout, LLh, nel * 2, flags)) return r;
   return finish(h, flags);
 }
@@ -488,12 +502,7 @@ int qt_nll_batch(qt_handle_t* h, const double* x, const int64_t* counts, int B, 
   if (int r = stage_in(h, h->in1, counts, (size_t)B * h->M, flags, &dc)) return r;
   if (int r = stage_out(h, h->out0, f, (size_t)B, flags, &df)) return r;
   if (int r = stage_out(h, h->out1, grad, nel, flags, &dg)) return r;
-  QT_SMALL_DISPATCH(h->nq, {
-    const size_t lds = small_lds_bytes<NQ>(h->M);
-    if (int r = check_lds(lds)) return r;
-    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
-    hipLaunchKernelGGL(qt::k_nll_batch<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dx, dc, B, df, dg);
-  });
+  QT_LAUNCH_SMALL(qt::k_nll_batch, h->M, B, (h->view(), dx, dc, B, df, dg));
   if (int r = fetch_out(h, df, f, (size_t)B, flags)) return r;
   if (int r = fetch_out(h, dg, grad, nel, flags)) return r;
   return finish(h, flags);
@@ -523,15 +532,10 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
   HIPCHK(h->ws_act.ensure((size_t)B * sizeof(int32_t)));
   double *wx = h->ws_x.as<double>(), *wg = h->ws_g.as<double>(), *wf = h->ws_f.as<double>();
   int32_t* wact = h->ws_act.as<int32_t>();
-  QT_SMALL_DISPATCH(h->nq, {
-    const size_t lds = small_lds_bytes<NQ>(h->M);
-    if (int r = check_lds(lds)) return r;
-    const int grid = (B + qt::Small<NQ>::TPW - 1) / qt::Small<NQ>::TPW;
-    hipLaunchKernelGGL(qt::k_mle_start<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dc, B, init, max_iter, tol,
-                       drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact);
-    hipLaunchKernelGGL(qt::k_mle_bfgs<NQ>, dim3(grid), dim3(64), lds, h->stream, h->view(), dc, B, max_iter, tol, drho,
-                       dnit, dnfev, dfun, dst, wx, wg, wf, wact);
-  });
+  QT_LAUNCH_SMALL(qt::k_mle_start, h->M, B,
+                  (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+  QT_LAUNCH_SMALL(qt::k_mle_bfgs, h->M, B,
+                  (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
   if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;
   if (int r = fetch_out(h, dnit, nit, (size_t)B, flags)) return r;
   if (int r = fetch_out(h, dnfev, nfev, (size_t)B, flags)) return r;

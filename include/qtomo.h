@@ -79,6 +79,11 @@ int qt_povm_kron(qt_handle_t* h, const double* povm1, int S1, int K1, double* ou
  * reference's n_measurements).  Every later estimator call on this handle uses this POVM and
  * assumes each trial's per-setting totals equal Ns. */
 int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns, int flags);
+/* The same for a POVM given as a one-qubit table povm1[S1][K1][4] to be tensored n times
+ * (measurements.py:88-93: every built-in POVM and every array whose last axis is 4).  Builds the
+ * full tensor on the device and, in addition, keeps the factorised form: the estimators then
+ * contract qubit by qubit instead of over the dense M x D operand.  Ns[S1^n]. */
+int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, const double* Ns, int flags);
 /* out[D][M]: the cached left inverse (for inspection / tests) */
 int qt_get_left_inverse(qt_handle_t* h, double* out, int flags);
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     "qt_pauli_basis": (_c_int, [_vp, _vp, _c_int]),
     "qt_povm_kron": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _c_int]),
     "qt_set_povm": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _c_int]),
+    "qt_set_povm_product": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _c_int]),
     "qt_get_left_inverse": (_c_int, [_vp, _vp, _c_int]),
     "qt_left_inverse": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int]),
     "qt_born_probs": (_c_int, [_vp, _vp, _c_int, _vp, _c_int]),

@@ -69,6 +69,9 @@ struct qt_handle {
   bool povm_set = false;
   int S = 0, K = 0, M = 0;
   DevBuf A, AT, Aw, AwT, Pinv, PinvT, Ns, aug, info;
+  // product-POVM (Kronecker) description, valid when prod.enabled
+  DevBuf pr_T, pr_P1, pr_P1T, pr_wrow, pr_rmap, pr_fwd, pr_bwd, pr_aug;
+  qt::ProductView prod{};
   // staging for host-pointer calls
   DevBuf in0, in1, out0, out1, out2, out3, out4, proc_aug;
   // MLE hand-off between k_mle_start and k_mle_bfgs
@@ -77,7 +80,7 @@ struct qt_handle {
   qt::ProcessState proc;
   bool proc_set = false;
 
-  qt::PovmView view() const { return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M}; }
+  qt::PovmView view() const { return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod}; }
 };
 
 namespace {
@@ -141,6 +144,10 @@ int count_bad(const int32_t* status, int B, int flags) {
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;  // LDS per CU on gfx950; one workgroup may use all of it
+// Measured (profiles/round1_v3_*): a lone wave per SIMD pays ~7-10 ns of issue per LDS read, more than
+// for a global load that lands asynchronously, and the image costs occupancy at large batch: the L2
+// streaming variant is faster in both regimes, so the image variant is kept but not selected.
+constexpr bool kPreferLdsImage = false;
 
 // Launch KERNEL<NQ, ALDS> for the handle's n: the LDS-image variant when image + scratch fit in
 // 160 KB, else the variant that streams the operand from L2.  ARGS is the parenthesised argument list.
@@ -156,7 +163,7 @@ int allow_big_lds(K kernel, size_t bytes) {
 #define QT_LAUNCH_ONE(KERNEL, NQV, ALDSV, M_, B_, ARGS)                                                   \
   do {                                                                                                    \
     using S_ = qt::Small<NQV, ALDSV>;                                                                     \
-    const size_t lds_ = S_::lds_bytes(M_);                                                                \
+    const size_t lds_ = S_::lds_bytes(M_, h->prod.enabled ? h->prod.R1 : 0);                              \
     if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for the n<=3 kernels (%zu B of LDS)", lds_); \
     if (int r_ = allow_big_lds(KERNEL<NQV, ALDSV>, lds_)) return r_;                                      \
     const int grid_ = ((B_) + S_::TPB - 1) / S_::TPB;                                                     \
@@ -165,7 +172,7 @@ int allow_big_lds(K kernel, size_t bytes) {
 #define QT_UNPACK(...) __VA_ARGS__
 #define QT_LAUNCH_N(KERNEL, NQV, M_, B_, ARGS)                          \
   do {                                                                  \
-    if (qt::Small<NQV, true>::lds_bytes(M_) <= kLdsLimit)               \
+    if (kPreferLdsImage && qt::Small<NQV, true>::lds_bytes(M_, h->prod.enabled ? h->prod.R1 : 0) <= kLdsLimit) \
       QT_LAUNCH_ONE(KERNEL, NQV, true, M_, B_, ARGS);                   \
     else                                                                \
       QT_LAUNCH_ONE(KERNEL, NQV, false, M_, B_, ARGS);                  \
@@ -244,6 +251,7 @@ void qt_destroy(qt_handle_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  for (DevBuf* b : {&h->pr_T, &h->pr_P1, &h->pr_P1T, &h->pr_wrow, &h->pr_rmap, &h->pr_fwd, &h->pr_bwd, &h->pr_aug}) b->release();
   for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->in0, &h->in1,
                     &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug, &h->ws_x, &h->ws_g, &h->ws_f,
                     &h->ws_act})
@@ -321,27 +329,10 @@ int qt_povm_kron(qt_handle_t* h, const double* povm1, int S1, int K1, double* ou
   return finish(h, flags);
 }
 
-int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns, int flags) {
-  if (int r = check_handle(h)) return r;
-  if (!A || !Ns || S < 1 || K < 1) return fail(QT_ERR_ARG, "bad set_povm arguments");
+// Shared tail of qt_set_povm / qt_set_povm_product: h->A ([M][D]) and h->Ns ([S]) are on the device.
+static int finish_set_povm(qt_handle_t* h, int S, int K) {
   const int D = h->D;
   const size_t M = (size_t)S * K;
-  if (M < (size_t)D) return fail(QT_ERR_SINGULAR, "POVM has %zu rows < D = %d: not informationally complete", M, D);
-  h->povm_set = false;
-  h->proc_set = false;
-  const size_t bytes = M * D * sizeof(double);
-  HIPCHK(h->A.ensure(bytes));
-  HIPCHK(h->AT.ensure(bytes));
-  HIPCHK(h->Aw.ensure(bytes));
-  HIPCHK(h->AwT.ensure(bytes));
-  HIPCHK(h->Pinv.ensure(bytes));
-  HIPCHK(h->PinvT.ensure(bytes));
-  HIPCHK(h->Ns.ensure(S * sizeof(double)));
-  HIPCHK(h->aug.ensure((size_t)D * 2 * D * sizeof(double)));
-  HIPCHK(h->info.ensure(sizeof(int)));
-  const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  HIPCHK(hipMemcpyAsync(h->A.p, A, bytes, kind, h->stream));
-  HIPCHK(hipMemcpyAsync(h->Ns.p, Ns, S * sizeof(double), kind, h->stream));
   double *dA = h->A.as<double>(), *dAT = h->AT.as<double>(), *dAw = h->Aw.as<double>(), *dAwT = h->AwT.as<double>();
   double *dP = h->Pinv.as<double>(), *dPT = h->PinvT.as<double>(), *aug = h->aug.as<double>();
   hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dA, (int)M, D, dAT);
@@ -365,6 +356,143 @@ int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns,
   h->K = K;
   h->M = (int)M;
   h->povm_set = true;
+  return 0;
+}
+
+static int alloc_povm(qt_handle_t* h, int S, int K) {
+  const int D = h->D;
+  const size_t M = (size_t)S * K;
+  if (M < (size_t)D) return fail(QT_ERR_SINGULAR, "POVM has %zu rows < D = %d: not informationally complete", M, D);
+  h->povm_set = false;
+  h->proc_set = false;
+  h->prod = qt::ProductView{};
+  const size_t bytes = M * D * sizeof(double);
+  HIPCHK(h->A.ensure(bytes));
+  HIPCHK(h->AT.ensure(bytes));
+  HIPCHK(h->Aw.ensure(bytes));
+  HIPCHK(h->AwT.ensure(bytes));
+  HIPCHK(h->Pinv.ensure(bytes));
+  HIPCHK(h->PinvT.ensure(bytes));
+  HIPCHK(h->Ns.ensure(S * sizeof(double)));
+  HIPCHK(h->aug.ensure((size_t)D * 2 * D * sizeof(double)));
+  HIPCHK(h->info.ensure(sizeof(int)));
+  return 0;
+}
+
+int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (!A || !Ns || S < 1 || K < 1) return fail(QT_ERR_ARG, "bad set_povm arguments");
+  if (int r = alloc_povm(h, S, K)) return r;
+  const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(hipMemcpyAsync(h->A.p, A, (size_t)S * K * h->D * sizeof(double), kind, h->stream));
+  HIPCHK(hipMemcpyAsync(h->Ns.p, Ns, S * sizeof(double), kind, h->stream));
+  return finish_set_povm(h, S, K);
+}
+
+int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, const double* Ns, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (!povm1 || !Ns || S1 < 1 || K1 < 1) return fail(QT_ERR_ARG, "bad set_povm_product arguments");
+  const int n = h->nq, D = h->D, R1 = S1 * K1;
+  long long S = 1, K = 1, M = 1;
+  for (int q = 0; q < n; ++q) {
+    S *= S1;
+    K *= K1;
+    M *= R1;
+  }
+  if (M > (1 << 15)) return fail(QT_ERR_UNSUPPORTED, "product POVM with %lld rows is too large", M);
+  if (int r = alloc_povm(h, (int)S, (int)K)) return r;
+  // host copies of the small inputs (table and shots) for the index tables
+  std::vector<double> t1((size_t)R1 * 4), ns((size_t)S);
+  if (flags & QT_DEVICE_PTR) {
+    HIPCHK(hipMemcpy(t1.data(), povm1, t1.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ns.data(), Ns, ns.size() * sizeof(double), hipMemcpyDeviceToHost));
+  } else {
+    memcpy(t1.data(), povm1, t1.size() * sizeof(double));
+    memcpy(ns.data(), Ns, ns.size() * sizeof(double));
+  }
+  HIPCHK(h->pr_T.ensure(t1.size() * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(h->pr_T.p, t1.data(), t1.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->Ns.p, ns.data(), ns.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // full tensor (Born kernel, dense fallbacks, process tomography) -- a2, same kernel as qt_povm_kron
+  hipLaunchKernelGGL(qt::k_povm_kron, dim3(grid_for((size_t)M * D)), dim3(256), 0, h->stream, n, h->pr_T.as<double>(), S1,
+                     K1, h->A.as<double>());
+  if (int r = finish_set_povm(h, (int)S, (int)K)) return r;
+  // pinv of the one-qubit table, on the device: inv(T^T T) T^T  ([4][R1]) and its transpose
+  HIPCHK(h->pr_P1.ensure((size_t)4 * R1 * sizeof(double)));
+  HIPCHK(h->pr_P1T.ensure((size_t)4 * R1 * sizeof(double)));
+  HIPCHK(h->pr_aug.ensure((size_t)4 * 8 * sizeof(double)));
+  {
+    double *T = h->pr_T.as<double>(), *g = h->pr_aug.as<double>(), *P1 = h->pr_P1.as<double>();
+    hipLaunchKernelGGL(qt::k_gemm<0>, dim3(1, 1), dim3(256), 0, h->stream, 4, 4, R1, T, 4, 1, T, 4, 0, g, 8);
+    hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, 4, g, h->info.as<int>());
+    hipLaunchKernelGGL(qt::k_gemm<0>, dim3((R1 + 15) / 16, 1), dim3(256), 0, h->stream, 4, R1, 4, g + 4, 8, 0, T, 4, 1, P1,
+                       R1);
+    hipLaunchKernelGGL(qt::k_transpose, dim3(1), dim3(256), 0, h->stream, P1, 4, R1, h->pr_P1T.as<double>());
+  }
+  // host-side index bookkeeping: R-order row map, shot weights, stage tables
+  double tot = 0.0;
+  bool uniform = true;
+  for (long long s = 0; s < S; ++s) {
+    tot += ns[s];
+    if (ns[s] != ns[0]) uniform = false;
+  }
+  std::vector<int> rmap((size_t)M), fwd, bwd;
+  std::vector<double> wrow((size_t)M);
+  for (long long mr = 0; mr < M; ++mr) {  // mr = [r_1 .. r_n], r_q = s_q K1 + o_q
+    long long rem = mr, s = 0, o = 0, sp = 1, op = 1;
+    for (int q = n - 1; q >= 0; --q) {
+      const int r = (int)(rem % R1);
+      rem /= R1;
+      s += (r / K1) * sp;
+      o += (r % K1) * op;
+      sp *= S1;
+      op *= K1;
+    }
+    rmap[mr] = (int)(s * K + o);
+    wrow[mr] = ns[s] / tot;
+  }
+  auto ipow = [](long long b, int e) {
+    long long r = 1;
+    for (int i = 0; i < e; ++i) r *= b;
+    return r;
+  };
+  for (int q = 1; q <= n; ++q) {  // forward stage q: out[r_1..r_q][k_(q+1)..k_n]
+    const long long Kq = ipow(4, n - q), n_out = ipow(R1, q) * Kq;
+    for (long long o = 0; o < n_out; ++o) {
+      const long long rpre = o / (R1 * Kq), rq = (o / Kq) % R1, krest = o % Kq;
+      fwd.push_back((int)((rpre * 4 * Kq + krest) | (rq << 16)));
+    }
+  }
+  for (int q = n; q >= 1; --q) {  // backward stage q: out[r_1..r_(q-1)][k_q..k_n]
+    const long long Kq = ipow(4, n - q), n_out = ipow(R1, q - 1) * 4 * Kq;
+    for (long long o = 0; o < n_out; ++o) {
+      const long long rpre = o / (4 * Kq), kq = (o / Kq) % 4, krest = o % Kq;
+      bwd.push_back((int)((rpre * R1 * Kq + krest) | (kq << 16)));
+    }
+  }
+  HIPCHK(h->pr_rmap.ensure(rmap.size() * sizeof(int)));
+  HIPCHK(h->pr_wrow.ensure(wrow.size() * sizeof(double)));
+  HIPCHK(h->pr_fwd.ensure(fwd.size() * sizeof(int)));
+  HIPCHK(h->pr_bwd.ensure(bwd.size() * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(h->pr_rmap.p, rmap.data(), rmap.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->pr_wrow.p, wrow.data(), wrow.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->pr_fwd.p, fwd.data(), fwd.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->pr_bwd.p, bwd.data(), bwd.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  int info = 0;
+  HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (info != 0) return fail(QT_ERR_SINGULAR, "the one-qubit table is not informationally complete");
+  h->prod.T = h->pr_T.as<double>();
+  h->prod.P1T = h->pr_P1T.as<double>();
+  h->prod.wrowR = h->pr_wrow.as<double>();
+  h->prod.rmap = h->pr_rmap.as<int>();
+  h->prod.fwd = h->pr_fwd.as<int>();
+  h->prod.bwd = h->pr_bwd.as<int>();
+  h->prod.R1 = R1;
+  h->prod.uniform = uniform ? 1 : 0;
+  h->prod.wuni = ns[0] / tot;
+  h->prod.enabled = 1;
   return 0;
 }
 
@@ -466,7 +594,7 @@ int qt_chol_param(qt_handle_t* h, const double* rho, int B, double* x, int32_t* 
   if (int r = stage_in(h, h->in0, rho, nel * 2, flags, &din)) return r;
   if (int r = stage_out(h, h->out0, x, nel, flags, &dx)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
-  qt::PovmView pv{nullptr, nullptr, nullptr, 0};
+  qt::PovmView pv{nullptr, nullptr, nullptr, 0, qt::ProductView{}};
   QT_LAUNCH_SMALL_NOIMG(qt::k_chol_param, B, (pv, din, B, dx, dst));
   if (int r = fetch_out(h, dx, x, nel, flags)) return r;
   if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
@@ -483,7 +611,7 @@ int qt_chol_unparam(qt_handle_t* h, const double* x, int B, double* LLh, int fla
   const size_t nel = (size_t)B * h->D;
   if (int r = stage_in(h, h->in0, x, nel, flags, &din)) return r;
   if (int r = stage_out(h, h->out0, LLh, nel * 2, flags, &dout)) return r;
-  qt::PovmView pv{nullptr, nullptr, nullptr, 0};
+  qt::PovmView pv{nullptr, nullptr, nullptr, 0, qt::ProductView{}};
   QT_LAUNCH_SMALL_NOIMG(qt::k_chol_unparam, B, (pv, din, B, dout));
   if (int r = fetch_out(h, dout, LLh, nel * 2, flags)) return r;
   return finish(h, flags);

@@ -121,19 +121,27 @@ class Engine:
     # ---- a5 ---------------------------------------------------------------------------------
     def set_povm(self, povm_matrix, n_meas):
         """Cache A (S, K, D), the shot weights and the left inverse.  Re-uploading the same
-        (povm, shots) pair is skipped."""
-        a = _f64(povm_matrix)
+        (povm, shots) pair is skipped.  A tensor that carries its one-qubit factor
+        (measurements.PovmTensor) is registered in factorised form (qt_set_povm_product)."""
+        factor = povm_matrix.valid_factor() if hasattr(povm_matrix, "valid_factor") else None
+        a = _f64(np.asarray(povm_matrix))
         if a.ndim == 2:
             a = a[None]
         s, k, dd = a.shape
         if dd != self.D:
             raise ValueError("Incorrect POVM matrix")
         ns = _f64(np.broadcast_to(np.asarray(n_meas, dtype=np.float64), (s,)))
-        key = (a.shape, a.tobytes(), ns.tobytes())
+        key = (a.shape, a.tobytes(), ns.tobytes(), None if factor is None else factor.tobytes())
         if key == self._povm_key:
             return
         self._povm_key = None
-        self._chk(self.lib.qt_set_povm(self._h, _ptr(a), s, k, _ptr(ns), _capi.QT_HOST_PTR))
+        if factor is not None and (factor.shape[0] ** self.n, factor.shape[1] ** self.n) == (s, k):
+            self._chk(self.lib.qt_set_povm_product(self._h, _ptr(factor), factor.shape[0], factor.shape[1], _ptr(ns),
+                                                   _capi.QT_HOST_PTR))
+            self.product = True
+        else:
+            self._chk(self.lib.qt_set_povm(self._h, _ptr(a), s, k, _ptr(ns), _capi.QT_HOST_PTR))
+            self.product = False
         self._povm_key = key
         self.S, self.K, self.M = s, k, s * k
 

@@ -20,6 +20,35 @@ _ONE_QUBIT = {
 }
 
 
+class PovmTensor(np.ndarray):
+    """The (S, K, 4^n) POVM tensor as a plain ndarray that also remembers the one-qubit table it is the
+    n-fold tensor power of (`factor`, shape (S1, K1, 4)).  The engine uses the factor to contract
+    qubit by qubit (qt_set_povm_product); anything derived from the array (slices, arithmetic,
+    np.vstack, np.asarray) is ordinary data without a factor, and a checksum guards against
+    in-place edits of the tensor."""
+
+    def __new__(cls, tensor, factor):
+        obj = np.ascontiguousarray(tensor, dtype=np.float64).view(cls)
+        obj.factor = np.ascontiguousarray(factor, dtype=np.float64)
+        obj._digest = cls._checksum(obj)
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.factor = None
+        self._digest = None
+
+    @staticmethod
+    def _checksum(arr):
+        flat = np.asarray(arr).ravel()
+        return (arr.shape, float(flat.sum()), float(np.abs(flat).sum()), float(flat[:: max(1, flat.size // 97)].sum()))
+
+    def valid_factor(self):
+        """The one-qubit table, or None when the tensor no longer is its tensor power."""
+        if self.factor is None or self._digest != self._checksum(self):
+            return None
+        return self.factor
+
+
 def generate_measurement_matrix(povm="proj", n_qubits=1):
     """POVM tensor of shape (settings, outcomes, 4^n_qubits).
 
@@ -45,5 +74,5 @@ def generate_measurement_matrix(povm="proj", n_qubits=1):
     if table.ndim == 2:
         table = table[None, :, :]
     if n_qubits == 1:
-        return table
-    return get_engine(n_qubits).povm_kron(table)
+        return PovmTensor(table, table)
+    return PovmTensor(get_engine(n_qubits).povm_kron(table), table)

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="trials timed on the CPU oracle")
     ap.add_argument("--bootstrap-points", type=int, default=2000)
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
+    ap.add_argument("--share-gpu0", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -57,10 +59,15 @@ def main():
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    dev_index = 0 if args.share_gpu0 else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     import quantpy_amd as qp
     from quantpy_amd.tomography.state import simulate_counts
@@ -79,7 +86,7 @@ def main():
     all_counts = np.stack([simulate_counts(povm, bloch, shots) for _ in range(B * world)])
     counts = all_counts[rank * B:(rank + 1) * B]
 
-    eng = qp.get_engine(n, device=local_rank)
+    eng = qp.get_engine(n, device=dev_index)
     eng.set_povm(povm, shots)
     counts_d = torch.from_numpy(np.ascontiguousarray(counts)).cuda()
     rho_d = torch.empty((B, d, d), dtype=torch.complex128, device="cuda")
@@ -111,7 +118,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -131,12 +138,19 @@ def main():
     flops_eval = 4 * M * D + 16 * D * d + 2 * 8 * d**3
     flops_trial = 2 * M * D + 8 * D * d + 60 * 8 * d**3 + float(nfev.mean()) * flops_eval
     fp64_tflops = flops_trial * B / (kernel_ms * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
+    if B == 1000 and os.path.exists(pmc_file):  # HBM bytes per launch from the committed PMC passes
+        with open(pmc_file) as fh:
+            pmc = json.load(fh)
+        traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     roofline = {
-        "bound": "hbm", "kernel": "k_mle_batch<3>", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+        "bound": "hbm", "kernel": "k_mle_start<3,false> (+ k_mle_bfgs<3,false>, which exits at once when no trial iterates)", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+        "traffic_source": traffic_src,
         "bytes_per_launch": int(launch_bytes), "kernel_ms": round(kernel_ms, 5),
-        "note": "n=3 working set is LDS/register resident: the kernel is FP64-VALU/latency bound, not HBM bound "
-                "(SURVEY 8d); fp64 fraction reported beside it",
+        "note": "n=3 working set is LDS/register resident: the step is bound by single-wave instruction issue "
+                "(one wave per SIMD at B=1000), not by HBM (SURVEY 8d, DESIGN.md 4.1); algorithmic FP64 fraction beside it",
         "fp64": {"achieved": round(fp64_tflops, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": round(fp64_tflops / FP64_PEAK_TFLOPS, 6)},
     }
@@ -172,7 +186,7 @@ def main():
         barrier()
         boot_ms = (time.perf_counter() - tb) * 1e3
         if world > 1:
-            t = torch.tensor([boot_ms], dtype=torch.float64, device="cuda")
+            t = torch.tensor([boot_ms], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             boot_ms = float(t.item())
         boot = {"n_points": args.bootstrap_points, "wall_ms": round(boot_ms, 3), "scaling": "strong",

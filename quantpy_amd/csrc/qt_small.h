@@ -813,10 +813,12 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
     double* out = rho + ((size_t)b * D + c.l) * 2;
     out[0] = m.re / tr;
     out[1] = m.im / tr;
-    ws_x[(size_t)b * D + c.l] = xk;
-    ws_g[(size_t)b * D + c.l] = gk;
+    if (iterate) {  // the hand-off is written only for trials that go on to k_mle_bfgs
+      ws_x[(size_t)b * D + c.l] = xk;
+      ws_g[(size_t)b * D + c.l] = gk;
+    }
     if (c.l == 0) {
-      ws_f[b] = fk;
+      if (iterate) ws_f[b] = fk;
       ws_active[b] = iterate ? 1 : 0;
       if (nit_out) nit_out[b] = 0;
       if (nfev_out) nfev_out[b] = ok ? 1 : 0;
@@ -850,9 +852,10 @@ __global__ void __launch_bounds__(256) k_mle_bfgs(PovmView pv, const int64_t* __
   S::load_image(c, pv.Aw);
   S::load_freq(c, counts + (size_t)bb * pv.M);
 
-  double xk = ws_x[(size_t)bb * D + c.l];
-  double gk = ws_g[(size_t)bb * D + c.l];
-  double fk = ws_f[bb];
+  // inactive trials of a live wave idle through the loop on dummy finite values
+  double xk = mine ? ws_x[(size_t)b * D + c.l] : (c.l < S::d ? 1.0 : 0.0);
+  double gk = mine ? ws_g[(size_t)b * D + c.l] : 0.0;
+  double fk = mine ? ws_f[b] : 0.0;
   double H[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) H[k] = (k == c.l) ? 1.0 : 0.0;

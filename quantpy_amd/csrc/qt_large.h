@@ -1,0 +1,605 @@
+// Workgroup-per-trial kernels for n = 4, 5 qubits (D = 4^n = 256 / 1024 = one workgroup).
+//
+// The mapping of qt_small.h one level up: thread t of the workgroup is Bloch / parameter index
+// k = t AND matrix element (i, j) = (t / d, t % d) of every d x d complex matrix (d = 16 / 32), so the
+// same formulas apply with __syncthreads() in place of the wave fence and a two-level (DPP + LDS)
+// reduction in place of the DPP butterfly.  What changes is where things live:
+//   * LDS (<= 160 KB): L, the broadcast vector, and two overlaid work regions X / Y that hold the
+//     stages of the factorised POVM contraction (R-order, see qt_small.h) and, outside of it, the
+//     Jacobi images A / V and the gradient matrix.  At n = 5 with 'proj-set' (M = 6^5 = 7776):
+//     X = 7776, Y = 5184 doubles -> 127 KB.  Frequencies are not stored: they are re-read from the
+//     counts (int64, gathered through the R-order row map) when needed.
+//   * HBM: the BFGS inverse Hessian, D x D f64 per trial (0.5 MB at n = 4, 8 MB at n = 5) in a
+//     caller-provided workspace.  It is exactly symmetric by construction, so thread t reads column t
+//     (coalesced) for H g and for the rank-2 update; H0 = I is never materialised.  This is the one
+//     place on the path that is genuinely HBM-bound: 3 sweeps of H per BFGS iteration.
+// Estimators for n >= 4 require a product POVM (every built-in one is); a dense 7776 x 1024 operand
+// per evaluation per trial would be 64 MB of traffic and is refused rather than run slowly.
+//
+// Reference semantics: identical to qt_small.h (state.py:191-229, 267-273; routines.py:84-101).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qt_linesearch.h"
+#include "qt_small.h"
+
+namespace qt {
+
+template <int NQ>
+struct Large {
+  static constexpr int d = 1 << NQ;
+  static constexpr int D = d * d;
+  static constexpr int NT = D;          // threads per workgroup = one trial
+  static constexpr int NW = NT / 64;
+  static constexpr int T = d * (d - 1) / 2;
+  // LDS layout in doubles
+  static constexpr int oL = 0;                 // complex [d][d]
+  static constexpr int oVec = oL + 2 * D;      // [D]
+  static constexpr int oLam = oVec + D;        // [d]
+  static constexpr int oRed = oLam + d;        // [32] reduction scratch
+  static constexpr int oTab = oRed + 32;       // tabT [R1][4], tabP [R1][4]
+  __host__ __device__ static int x_doubles(int M) { return (M > 2 * D ? M : 2 * D) + (M & 1); }
+  __host__ __device__ static int y_doubles(int M, int R1) {
+    int y = (M / R1) * 4;  // R1^(n-1) * 4: the largest stage that lands in Y
+    if (y < 2 * D) y = 2 * D;
+    return y + (y & 1);
+  }
+  __host__ __device__ static size_t lds_bytes(int M, int R1) {
+    return (size_t)(oTab + 8 * R1 + x_doubles(M) + y_doubles(M, R1)) * sizeof(double);
+  }
+
+  struct Ctx {
+    int t, i, j;
+    double* sm;
+    int M;
+    ProductView pr;
+    const int64_t* counts;  // this trial's counts [M]
+    double tot;             // sum of counts
+    int xm, zm, ny;
+    int pi, pj, pkind;
+    __device__ __forceinline__ cd* L() const { return reinterpret_cast<cd*>(sm + oL); }
+    __device__ __forceinline__ double* vec() const { return sm + oVec; }
+    __device__ __forceinline__ double* lam() const { return sm + oLam; }
+    __device__ __forceinline__ double* red() const { return sm + oRed; }
+    __device__ __forceinline__ double* tabT() const { return sm + oTab; }
+    __device__ __forceinline__ double* tabP() const { return sm + oTab + 4 * pr.R1; }
+    __device__ __forceinline__ double* X() const { return sm + oTab + 8 * pr.R1; }
+    __device__ __forceinline__ double* Y() const { return X() + x_doubles(M); }
+    __device__ __forceinline__ cd* Aimg() const { return reinterpret_cast<cd*>(Y()); }  // overlays Y
+    __device__ __forceinline__ cd* Vimg() const { return reinterpret_cast<cd*>(X()); }  // overlays X
+  };
+
+  // ---- workgroup reductions: identical bits in every thread ----------------------------------
+  __device__ static double bsum(const Ctx& c, double v) {
+    v = gsum<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) c.red()[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += c.red()[w];
+    return s;
+  }
+  __device__ static double bmax(const Ctx& c, double v) {
+    v = gmax<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) c.red()[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = c.red()[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s = nanmax(s, c.red()[w]);
+    return s;
+  }
+
+  __device__ static void make_ctx(Ctx& c, double* smem, const PovmView& pv, const int64_t* counts) {
+    c.t = threadIdx.x;
+    c.i = c.t / d;
+    c.j = c.t % d;
+    c.sm = smem;
+    c.M = pv.M;
+    c.pr = pv.pr;
+    c.counts = counts;
+    int xm = 0, zm = 0, ny = 0;
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+      const int dig = (c.t >> (2 * b)) & 3;
+      if (dig == 1 || dig == 2) xm |= 1 << b;
+      if (dig == 2 || dig == 3) zm |= 1 << b;
+      if (dig == 2) ++ny;
+    }
+    c.xm = xm;
+    c.zm = zm;
+    c.ny = ny & 3;
+    if (c.t < d) {
+      c.pi = c.pj = c.t;
+      c.pkind = 0;
+    } else {
+      int tt = c.t - d;
+      c.pkind = 1;
+      if (tt >= T) {
+        tt -= T;
+        c.pkind = 2;
+      }
+      int ii = (int)((1.0 + sqrt(1.0 + 8.0 * tt)) * 0.5);  // row of np.tril_indices(d, -1)[tt]
+      while ((ii * (ii - 1)) / 2 > tt) --ii;
+      while ((ii * (ii + 1)) / 2 <= tt) ++ii;
+      c.pi = ii;
+      c.pj = tt - (ii * (ii - 1)) / 2;
+    }
+    for (int e = c.t; e < 4 * c.pr.R1; e += NT) {
+      c.tabT()[e] = c.pr.T[e];
+      c.tabP()[e] = c.pr.P1T[e];
+    }
+    double part = 0.0;
+    if (counts)
+      for (int m = c.t; m < c.M; m += NT) part += (double)counts[m];
+    c.tot = bsum(c, part);  // (barriers inside also publish the tables)
+  }
+  // frequency of R-order row o (state.py:193, :227)
+  __device__ __forceinline__ static double freq(const Ctx& c, int o) { return (double)c.counts[c.pr.rmap[o]] / c.tot; }
+
+  __device__ __forceinline__ static int pauli_index(int x, int z) {
+    int k = 0;
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+      const int xb = (x >> b) & 1, zb = (z >> b) & 1;
+      const int dig = xb ? (zb ? 2 : 1) : (zb ? 3 : 0);
+      k |= dig << (2 * b);
+    }
+    return k;
+  }
+  __device__ static double bloch_of(const Ctx& c, const cd* m) {
+    cd s{0.0, 0.0};
+    for (int r = 0; r < d; ++r) {
+      const cd e = m[r * d + (r ^ c.xm)];
+      const double sg = (__popc(r & c.zm) & 1) ? -1.0 : 1.0;
+      s.re += sg * e.re;
+      s.im -= sg * e.im;
+    }
+    const double v = c.ny == 0 ? s.re : c.ny == 1 ? s.im : c.ny == 2 ? -s.re : -s.im;
+    return v / d;
+  }
+  __device__ static cd matrix_of(const Ctx& c, const double* v) {
+    const int x = c.i ^ c.j;
+    cd s{0.0, 0.0};
+    for (int z = 0; z < d; ++z) {
+      const int k = pauli_index(x, z);
+      const double val = ((__popc(c.i & z) & 1) ? -1.0 : 1.0) * v[k];
+      switch (__popc(x & z) & 3) {
+        case 0: s.re += val; break;
+        case 1: s.im -= val; break;
+        case 2: s.re -= val; break;
+        default: s.im += val; break;
+      }
+    }
+    return s;
+  }
+
+  // ---- factorised contractions (qt_small.h for the scheme) -------------------------------------
+  __device__ __forceinline__ static int ipow(int b, int e) {
+    int r = 1;
+    for (int q = 0; q < e; ++q) r *= b;
+    return r;
+  }
+  template <bool FWD>
+  __device__ __forceinline__ static double stage_value(const double* tb, int R1, int ent, int stride, const double* in) {
+    const int base = ent & 0xffff, sel = ent >> 16;
+    if (FWD) {
+      const double* row = tb + sel * 4;
+      return fma(row[3], in[base + 3 * stride],
+                 fma(row[2], in[base + 2 * stride], fma(row[1], in[base + stride], row[0] * in[base])));
+    }
+    double acc = 0.0;
+    for (int r = 0; r < R1; ++r) acc = fma(tb[r * 4 + sel], in[base + r * stride], acc);
+    return acc;
+  }
+  template <bool FWD>
+  __device__ static void stage(const Ctx& c, const double* tb, const int* tab, int n_out, int stride, const double* in,
+                               double* out) {
+    for (int o = c.t; o < n_out; o += NT) out[o] = stage_value<FWD>(tb, c.pr.R1, tab[o], stride, in);
+    __syncthreads();
+  }
+  // Backward pass from Y_n held in X (R-order) to this thread's Y_0[k = t].  Stage n: X -> Y, then
+  // alternating; tb = tabT (A^T y) or tabP (A^+ f).
+  __device__ static double prod_backward(const Ctx& c, const double* tb) {
+    const int R1 = c.pr.R1;
+    const int* tab = c.pr.bwd;
+    const double* in = c.X();
+    double* bufs[2] = {c.Y(), c.X()};
+    int which = 0;
+    for (int q = NQ; q >= 2; --q) {
+      const int stride = 1 << (2 * (NQ - q));
+      const int n_out = ipow(R1, q - 1) * 4 * stride;
+      stage<false>(c, tb, tab, n_out, stride, in, bufs[which]);
+      tab += n_out;
+      in = bufs[which];
+      which ^= 1;
+    }
+    const double r = stage_value<false>(tb, R1, tab[c.t], 1 << (2 * (NQ - 1)), in);
+    __syncthreads();
+    return r;
+  }
+
+  // ---- a6: linear inversion (uniform shots: pinv(T)^(x n) / w; checked on the host) -------------
+  __device__ static cd lin_invert(const Ctx& c, double& bloch_t) {
+    for (int o = c.t; o < c.M; o += NT) c.X()[o] = freq(c, o);
+    __syncthreads();
+    bloch_t = prod_backward(c, c.tabP()) / (c.pr.wuni * d);
+    c.vec()[c.t] = bloch_t;
+    __syncthreads();
+    const cd r = matrix_of(c, c.vec());
+    __syncthreads();
+    return r;
+  }
+
+  // ---- a7: Jacobi eigenvalue clip (XOR order; one LDS round trip + one barrier pair per round) ---
+  __device__ static cd psd_project(const Ctx& c, cd a, double eps) {
+    const int i = c.i, j = c.j;
+    cd* Ai = c.Aimg();
+    cd* Vi = c.Vimg();
+    cd v{i == j ? 1.0 : 0.0, 0.0};
+    if (i == j) a.im = 0.0;
+    const double nrm = bsum(c, a.re * a.re + a.im * a.im);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+      const double off = bsum(c, i != j ? a.re * a.re + a.im * a.im : 0.0);
+      if (!(off > 1e-28 * nrm)) break;  // uniform: every thread holds the same sums
+      for (int r = 1; r < d; ++r) {
+        Ai[c.t] = a;
+        Vi[c.t] = v;
+        __syncthreads();
+        const int pj = j ^ r, pi = i ^ r;
+        const int cp = j < pj ? j : pj, cq = j < pj ? pj : j;
+        const int rp = i < pi ? i : pi, rq = i < pi ? pi : i;
+        const double c_pp = Ai[cp * d + cp].re, c_qq = Ai[cq * d + cq].re;
+        const cd c_pq = Ai[cp * d + cq];
+        const double r_pp = Ai[rp * d + rp].re, r_qq = Ai[rq * d + rq].re;
+        const cd r_pq = Ai[rp * d + rq];
+        const cd a_c = Ai[i * d + pj], a_r = Ai[pi * d + j], a_x = Ai[pi * d + pj];
+        const cd v_c = Vi[i * d + pj];
+        __syncthreads();
+        double cj, ci;
+        cd wj, wi;
+        rotation(c_pp, c_qq, c_pq, cj, wj);
+        rotation(r_pp, r_qq, r_pq, ci, wi);
+        if (j < pj) wj = cd{-wj.re, wj.im};
+        if (i < pi) wi = cd{-wi.re, wi.im};
+        const cd t0 = cadd(cscale(a, cj), cmul(a_c, wj));
+        const cd t1 = cadd(cscale(a_r, cj), cmul(a_x, wj));
+        a = cadd(cscale(t0, ci), cmulc(t1, wi));
+        v = cadd(cscale(v, cj), cmul(v_c, wj));
+        if (i == j) a.im = 0.0;
+      }
+    }
+    double* lam = c.lam();
+    Vi[c.t] = v;
+    if (i == j) lam[i] = a.re;
+    __syncthreads();
+    cd rr{0.0, 0.0};
+    for (int k = 0; k < d; ++k) {
+      const double lc = lam[k] > eps ? lam[k] : eps;
+      const cd p = cmulc(Vi[i * d + k], Vi[j * d + k]);
+      rr.re += lc * p.re;
+      rr.im += lc * p.im;
+    }
+    const double tr = bsum(c, i == j ? rr.re : 0.0);
+    return cd{rr.re / tr, rr.im / tr};
+  }
+
+  // ---- a8: Cholesky (image in the A overlay, factor in L) ------------------------------------------
+  __device__ static double cholesky_param(const Ctx& c, cd a, int& ok) {
+    cd* A = c.Aimg();
+    cd* L = c.L();
+    const int i = c.i, j = c.j;
+    A[c.t] = a;
+    L[c.t] = cd{0.0, 0.0};
+    ok = 1;
+    __syncthreads();
+    for (int k = 0; k < d; ++k) {
+      const double akk = A[k * d + k].re;
+      if (!(akk > 0.0)) ok = 0;
+      const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
+      const cd aik = A[i * d + k], ajk = A[j * d + k];
+      const cd lik{aik.re * rs, aik.im * rs}, ljk{ajk.re * rs, ajk.im * rs};
+      if (j == k && i >= k) L[c.t] = (i == k) ? cd{akk * rs, 0.0} : lik;
+      if (i > k && j > k) {
+        const cd p = cmulc(lik, ljk);
+        a.re -= p.re;
+        a.im -= p.im;
+        A[c.t] = a;
+      }
+      __syncthreads();
+    }
+    const cd e = L[c.pi * d + c.pj];
+    const double x = c.pkind == 2 ? e.im : e.re;
+    __syncthreads();
+    return x;
+  }
+
+  __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out) {
+    int ok;
+    double x = cholesky_param(c, r, ok);
+    const double tr = bsum(c, c.i == c.j ? r.re : 0.0);
+    cd out{r.re / tr, r.im / tr};
+    x = x / sqrt(tr);
+    if (!ok) {  // uniform across the workgroup (one trial)
+      out = psd_project(c, r, 1e-15);
+      if (xl) x = cholesky_param(c, out, ok);
+      else ok = 1;
+    }
+    if (xl) *xl = x;
+    if (ok_out) *ok_out = ok;
+    return out;
+  }
+
+  __device__ static cd build_llh(const Ctx& c, double xt, double& tr) {
+    double* vx = c.vec();
+    cd* L = c.L();
+    vx[c.t] = xt;
+    tr = bsum(c, xt * xt);  // barriers inside publish vx
+    const int i = c.i, j = c.j;
+    cd lij{0.0, 0.0};
+    if (i == j) lij.re = vx[i];
+    else if (i > j) {
+      const int tt = (i * (i - 1)) / 2 + j;
+      lij = cd{vx[d + tt], vx[d + T + tt]};
+    }
+    L[c.t] = lij;
+    __syncthreads();
+    cd m{0.0, 0.0};
+    const int kmax = i < j ? i : j;
+    for (int k = 0; k <= kmax; ++k) m = cadd(m, cmulc(L[i * d + k], L[j * d + k]));
+    return m;
+  }
+
+  // ---- a9: NLL value + exact gradient (product POVM) -------------------------------------------------
+  __device__ static void nll_grad(const Ctx& c, double xt, double& f, double& gt) {
+    double tr;
+    const cd m = build_llh(c, xt, tr);
+    cd* A = c.Aimg();
+    A[c.t] = cd{m.re / tr, m.im / tr};
+    __syncthreads();
+    const double bl = bloch_of(c, A);
+    double* vec = c.vec();
+    vec[c.t] = bl;
+    __syncthreads();
+    const int R1 = c.pr.R1;
+    const int* tab = c.pr.fwd;
+    const double* in = vec;
+    for (int q = 1; q < NQ; ++q) {  // stages 1 .. n-1 alternate so that stage n-1 lands in Y
+      const int stride = 1 << (2 * (NQ - q));
+      const int n_out = ipow(R1, q) * stride;
+      double* out = ((NQ - 1 - q) & 1) ? c.X() : c.Y();
+      stage<true>(c, c.tabT(), tab, n_out, stride, in, out);
+      tab += n_out;
+      in = out;
+    }
+    double fpart = 0.0;
+    for (int o = c.t; o < c.M; o += NT) {  // stage n fused with the likelihood terms; Y_n -> X
+      const double xn = stage_value<true>(c.tabT(), R1, tab[o], 1, in);
+      const double wrow = c.pr.wrowR[o];
+      const double pe = xn * wrow * d + 1e-10;
+      const double fr = freq(c, o);
+      fpart += fr * log(pe);
+      c.X()[o] = wrow * fr / pe;
+    }
+    f = -bsum(c, fpart);  // barriers inside publish X
+    const double wl = prod_backward(c, c.tabT());
+    const double tr_g_rho = -(double)d * bsum(c, wl * bl);
+    vec[c.t] = wl;
+    __syncthreads();
+    cd g = matrix_of(c, vec);
+    g.re = -g.re;
+    g.im = -g.im;
+    if (c.i == c.j) g.re -= tr_g_rho;
+    g.re /= tr;
+    g.im /= tr;
+    A[c.t] = g;
+    __syncthreads();
+    const cd* L = c.L();
+    cd q{0.0, 0.0};
+    for (int k = c.pj; k < d; ++k) q = cadd(q, cmul(A[c.pi * d + k], L[k * d + c.pj]));
+    gt = 2.0 * (c.pkind == 2 ? q.im : q.re);
+    __syncthreads();
+  }
+};
+
+// =========================================================================================
+// kernels: one workgroup (D threads) per trial; dynamic LDS = Large<NQ>::lds_bytes(M, R1)
+// =========================================================================================
+
+template <int NQ>
+__global__ void __launch_bounds__(Large<NQ>::NT) k_lin_large(PovmView pv, const int64_t* __restrict__ counts, int B,
+                                                             int physical, double* __restrict__ rho,
+                                                             double* __restrict__ bloch_out, int32_t* __restrict__ status) {
+  using S = Large<NQ>;
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  typename S::Ctx c;
+  S::make_ctx(c, smem, pv, counts + (size_t)b * pv.M);
+  double bl;
+  cd r = S::lin_invert(c, bl);
+  if (physical) r = S::make_feasible(c, r, nullptr, nullptr);
+  double* out = rho + ((size_t)b * S::D + c.t) * 2;
+  out[0] = r.re;
+  out[1] = r.im;
+  if (bloch_out) bloch_out[(size_t)b * S::D + c.t] = bl;
+  if (status && c.t == 0) status[b] = (r.re == r.re) ? 0 : 4;
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(Large<NQ>::NT) k_chol_param_large(PovmView pv, const double* __restrict__ rho, int B,
+                                                                    double* __restrict__ x, int32_t* __restrict__ status) {
+  using S = Large<NQ>;
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  typename S::Ctx c;
+  S::make_ctx(c, smem, pv, nullptr);
+  const double* in = rho + ((size_t)b * S::D + c.t) * 2;
+  int ok;
+  const double xt = S::cholesky_param(c, cd{in[0], in[1]}, ok);
+  x[(size_t)b * S::D + c.t] = xt;
+  if (status && c.t == 0) status[b] = ok ? 0 : 1;
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(Large<NQ>::NT) k_chol_unparam_large(PovmView pv, const double* __restrict__ x, int B,
+                                                                      double* __restrict__ llh) {
+  using S = Large<NQ>;
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  typename S::Ctx c;
+  S::make_ctx(c, smem, pv, nullptr);
+  double tr;
+  const cd m = S::build_llh(c, x[(size_t)b * S::D + c.t], tr);
+  double* out = llh + ((size_t)b * S::D + c.t) * 2;
+  out[0] = m.re;
+  out[1] = m.im;
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(Large<NQ>::NT) k_nll_large(PovmView pv, const double* __restrict__ x,
+                                                             const int64_t* __restrict__ counts, int B,
+                                                             double* __restrict__ f, double* __restrict__ grad) {
+  using S = Large<NQ>;
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  typename S::Ctx c;
+  S::make_ctx(c, smem, pv, counts + (size_t)b * pv.M);
+  double fv, gt;
+  S::nll_grad(c, x[(size_t)b * S::D + c.t], fv, gt);
+  if (c.t == 0) f[b] = fv;
+  if (grad) grad[(size_t)b * S::D + c.t] = gt;
+}
+
+// a10 for n = 4, 5: the whole MLE of one trial.  `hess` = B x D x D doubles of workspace.
+template <int NQ>
+__global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const int64_t* __restrict__ counts, int B,
+                                                             int init, int max_iter, double gtol, double* __restrict__ rho,
+                                                             int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
+                                                             double* __restrict__ fun_out, int32_t* __restrict__ status_out,
+                                                             double* __restrict__ hess) {
+  using S = Large<NQ>;
+  constexpr int D = S::D, d = S::d;
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  typename S::Ctx c;
+  S::make_ctx(c, smem, pv, counts + (size_t)b * pv.M);
+  int ok;
+  double xk;
+  if (init == 0) {
+    double bl;
+    const cd lin = S::lin_invert(c, bl);
+    S::make_feasible(c, lin, &xk, &ok);
+  } else {
+    xk = S::cholesky_param(c, cd{c.i == c.j ? 1.0 / d : 0.0, 0.0}, ok);
+  }
+  double fk = 0.0, gk = 0.0;
+  int kiter = 0, nfev = 0, status = ok ? 0 : 1;
+  bool active = ok != 0;
+  if (active) {
+    S::nll_grad(c, xk, fk, gk);
+    nfev = 1;
+    const double gnorm = S::bmax(c, fabs(gk));
+    if (!(gnorm > gtol) || !(0 < max_iter)) active = false;
+  }
+  double* H = hess + (size_t)b * D * D;  // symmetric: thread t works on column t (H[k*D + t])
+  bool h_identity = true;
+  double old_old = 0.0, pk = 0.0, stp = 0.0;
+  LineSearch ls;
+  double* vec = c.vec();
+  if (active) {
+    old_old = fk + sqrt(S::bsum(c, gk * gk)) / 2.0;
+    pk = -gk;
+    ls.start(fk, old_old, S::bsum(c, gk * pk), &stp);
+  }
+  const int eval_cap = (max_iter + 2) * 130;
+  while (active) {  // uniform: one trial per workgroup, every thread holds the same scalars
+    double ft, gt;
+    S::nll_grad(c, xk + stp * pk, ft, gt);
+    if (++nfev > eval_cap) {
+      status = 2;
+      break;
+    }
+    const double dphi = S::bsum(c, gt * pk);
+    double next = stp;
+    const int r = ls.advance(stp, ft, dphi, &next);
+    if (r == LS_EVAL) {
+      stp = next;
+      continue;
+    }
+    if (r == LS_FAIL) {
+      status = 2;
+      break;
+    }
+    const double sk = stp * pk;
+    const double pnorm2 = S::bsum(c, pk * pk);
+    xk = xk + sk;
+    const double yk = gt - gk;
+    gk = gt;
+    old_old = fk;
+    fk = ft;
+    ++kiter;
+    const double gnorm = S::bmax(c, fabs(gk));
+    if (!(gnorm > gtol)) break;
+    if (stp * sqrt(pnorm2) <= 0.0) break;
+    if (!isfinite(fk)) {
+      status = 2;
+      break;
+    }
+    const double ys = S::bsum(c, yk * sk);
+    const double rhok = (ys == 0.0) ? 1000.0 : 1.0 / ys;
+    // u = H y ; H += -rho (u s^T + s u^T) + (rho^2 y.u + rho) s s^T   (column t per thread)
+    vec[c.t] = yk;
+    __syncthreads();
+    double u = 0.0;
+    if (h_identity) u = yk;
+    else
+      for (int k = 0; k < D; ++k) u = fma(H[(size_t)k * D + c.t], vec[k], u);
+    const double yhy = S::bsum(c, yk * u);
+    double* ub = c.X();  // u | s
+    ub[c.t] = u;
+    ub[D + c.t] = sk;
+    __syncthreads();
+    const double cc = rhok * rhok * yhy + rhok;
+    if (!(kiter < max_iter)) break;
+    vec[c.t] = gk;
+    __syncthreads();
+    // fused: update column t of H and accumulate (H_new g)_t in the same sweep
+    double hp = 0.0;
+    for (int k = 0; k < D; ++k) {
+      const double hold = h_identity ? (k == c.t ? 1.0 : 0.0) : H[(size_t)k * D + c.t];
+      const double hnew = hold + (-rhok * (ub[k] * sk + ub[D + k] * u) + cc * ub[D + k] * sk);
+      H[(size_t)k * D + c.t] = hnew;
+      hp = fma(hnew, vec[k], hp);
+    }
+    h_identity = false;
+    __syncthreads();
+    pk = -hp;
+    ls.start(fk, old_old, S::bsum(c, gk * pk), &stp);
+  }
+  if (status == 0 && ok) {
+    const double gn = S::bmax(c, fabs(gk));
+    const double xn = S::bmax(c, fabs(xk));
+    if (kiter >= max_iter) status = 3;
+    else if (gn != gn || fk != fk || xn != xn) status = 4;
+  }
+  double tr;
+  const cd m = S::build_llh(c, xk, tr);
+  double* out = rho + ((size_t)b * D + c.t) * 2;
+  out[0] = m.re / tr;
+  out[1] = m.im / tr;
+  if (c.t == 0) {
+    if (nit_out) nit_out[b] = kiter;
+    if (nfev_out) nfev_out[b] = nfev;
+    if (fun_out) fun_out[b] = fk;
+    if (status_out) status_out[b] = status;
+  }
+}
+
+}  // namespace qt

@@ -148,6 +148,33 @@ __device__ __forceinline__ double dot_lds(const double* img, int stride, int lan
   return (a0 + a1) + (a2 + a3);
 }
 
+// Unitary 2x2 rotation J = [[c, w], [-conj(w), c]] that (nearly) annihilates a_pq of
+// [[app, apq], [conj(apq), aqq]]: with delta = (aqq - app)/2 and
+// u = t/|apq| = sign(delta) / (|delta| + sqrt(delta^2 + |apq|^2)):  c = 1/sqrt(1 + u^2 |apq|^2),
+// w = s e^{i phi} = c u apq.  Only c has to be accurate (it makes J unitary for whatever u is
+// used); u comes from hardware seeds with one Newton step each (~1e-13): the rotated a_pq is
+// kept as computed instead of being set to zero, so an inexact angle costs convergence speed
+// (nothing measurable), never accuracy.
+__device__ __forceinline__ void rotation(double app, double aqq, cd apq, double& cs, cd& w) {
+  const double ab2 = apq.re * apq.re + apq.im * apq.im;
+  cs = 1.0;
+  w = cd{0.0, 0.0};
+  if (ab2 > 1e-300) {
+    const double dl = 0.5 * (aqq - app);
+    const double x = fma(dl, dl, ab2);
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(y * fma(-x * y, y, 1.0), 0.5, y);
+    const double den = fabs(dl) + x * y;  // |delta| + sqrt(delta^2 + |apq|^2)
+    double z = __builtin_amdgcn_rcp(den);
+    z = fma(z, fma(-den, z, 1.0), z);
+    const double u = copysign(z, dl);
+    cs = fast_rsqrt(fma(u * u, ab2, 1.0));
+    const double cu = cs * u;
+    w = cd{cu * apq.re, cu * apq.im};
+  }
+}
+
+
 // A POVM that is the n-fold tensor product of a one-qubit table T[R1][4] (every built-in POVM and
 // every array with a last axis of 4 -- measurements.py:88-93): the M x D contractions A' b, A'^T r and
 // A'^+ f factor into n small ones, qubit by qubit (R1^q 4^(n-q) outputs of 4 or R1 terms each), which
@@ -424,32 +451,6 @@ struct Small {
     cd r = matrix_of(c, c.vec());
     wave_sync();
     return r;
-  }
-
-  // Unitary 2x2 rotation J = [[c, w], [-conj(w), c]] that (nearly) annihilates a_pq of
-  // [[app, apq], [conj(apq), aqq]]: with delta = (aqq - app)/2 and
-  // u = t/|apq| = sign(delta) / (|delta| + sqrt(delta^2 + |apq|^2)):  c = 1/sqrt(1 + u^2 |apq|^2),
-  // w = s e^{i phi} = c u apq.  Only c has to be accurate (it makes J unitary for whatever u is
-  // used); u comes from hardware seeds with one Newton step each (~1e-13): the rotated a_pq is
-  // kept as computed instead of being set to zero, so an inexact angle costs convergence speed
-  // (nothing measurable), never accuracy.
-  __device__ __forceinline__ static void rotation(double app, double aqq, cd apq, double& cs, cd& w) {
-    const double ab2 = apq.re * apq.re + apq.im * apq.im;
-    cs = 1.0;
-    w = cd{0.0, 0.0};
-    if (ab2 > 1e-300) {
-      const double dl = 0.5 * (aqq - app);
-      const double x = fma(dl, dl, ab2);
-      double y = __builtin_amdgcn_rsq(x);
-      y = fma(y * fma(-x * y, y, 1.0), 0.5, y);
-      const double den = fabs(dl) + x * y;  // |delta| + sqrt(delta^2 + |apq|^2)
-      double z = __builtin_amdgcn_rcp(den);
-      z = fma(z, fma(-den, z, 1.0), z);
-      const double u = copysign(z, dl);
-      cs = fast_rsqrt(fma(u * u, ab2, 1.0));
-      const double cu = cs * u;
-      w = cd{cu * apq.re, cu * apq.im};
-    }
   }
 
   // ---- a7: eigenvalue clip + trace renormalisation by a parallel-order cyclic Jacobi.

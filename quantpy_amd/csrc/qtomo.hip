@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/qtomo.h"
+#include "qt_large.h"
 #include "qt_ops.h"
 #include "qt_process.h"
 #include "qt_small.h"
@@ -76,6 +77,8 @@ struct qt_handle {
   DevBuf in0, in1, out0, out1, out2, out3, out4, proc_aug;
   // MLE hand-off between k_mle_start and k_mle_bfgs
   DevBuf ws_x, ws_g, ws_f, ws_act;
+  // BFGS inverse Hessians of the n >= 4 kernels (D x D doubles per trial of a chunk)
+  DevBuf hess;
   // process tomography
   qt::ProcessState proc;
   bool proc_set = false;
@@ -193,6 +196,29 @@ int allow_big_lds(K kernel, size_t bytes) {
     default: return fail(QT_ERR_UNSUPPORTED, "estimators support n_qubits 1..3 in this release (got %d)", h->nq); \
   }
 
+// ---- n = 4, 5: workgroup-per-trial kernels (qt_large.h) ---------------------------------------------
+int need_product(qt_handle_t* h, bool need_uniform) {
+  if (!h->prod.enabled)
+    return fail(QT_ERR_UNSUPPORTED, "n_qubits = %d estimators need a product POVM (qt_set_povm_product): a dense %d x %d operand per evaluation is refused", h->nq, h->M, h->D);
+  if (need_uniform && !h->prod.uniform)
+    return fail(QT_ERR_UNSUPPORTED, "n_qubits = %d linear inversion needs equal shots per setting", h->nq);
+  return 0;
+}
+#define QT_LAUNCH_LARGE(KERNEL, B_, M_, R1_, ARGS)                                                          \
+  do {                                                                                                      \
+    if (h->nq == 4) {                                                                                       \
+      const size_t lds_ = qt::Large<4>::lds_bytes(M_, R1_);                                                 \
+      if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for LDS (%zu B)", lds_);         \
+      if (int r_ = allow_big_lds(KERNEL<4>, lds_)) return r_;                                               \
+      hipLaunchKernelGGL((KERNEL<4>), dim3(B_), dim3(qt::Large<4>::NT), lds_, h->stream, QT_UNPACK ARGS);   \
+    } else {                                                                                                \
+      const size_t lds_ = qt::Large<5>::lds_bytes(M_, R1_);                                                 \
+      if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for LDS (%zu B)", lds_);         \
+      if (int r_ = allow_big_lds(KERNEL<5>, lds_)) return r_;                                               \
+      hipLaunchKernelGGL((KERNEL<5>), dim3(B_), dim3(qt::Large<5>::NT), lds_, h->stream, QT_UNPACK ARGS);   \
+    }                                                                                                       \
+  } while (0)
+
 int need_povm(qt_handle_t* h) {
   if (!h->povm_set) return fail(QT_ERR_STATE, "qt_set_povm has not been called on this handle");
   return 0;
@@ -254,7 +280,7 @@ void qt_destroy(qt_handle_t* h) {
   for (DevBuf* b : {&h->pr_T, &h->pr_P1, &h->pr_P1T, &h->pr_wrow, &h->pr_rmap, &h->pr_fwd, &h->pr_bwd, &h->pr_aug}) b->release();
   for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->in0, &h->in1,
                     &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug, &h->ws_x, &h->ws_g, &h->ws_f,
-                    &h->ws_act})
+                    &h->ws_act, &h->hess})
     b->release();
   h->proc.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -575,7 +601,12 @@ int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, dou
   if (int r = stage_out(h, h->out0, rho, nel * 2, flags, &drho)) return r;
   if (int r = stage_out(h, h->out1, bloch_out, nel, flags, &dbl)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
-  QT_LAUNCH_SMALL(qt::k_lin_batch, h->M, B, (h->view(), dc, B, physical, drho, dbl, dst));
+  if (h->nq >= 4) {
+    if (int r = need_product(h, true)) return r;
+    QT_LAUNCH_LARGE(qt::k_lin_large, B, h->M, h->prod.R1, (h->view(), dc, B, physical, drho, dbl, dst));
+  } else {
+    QT_LAUNCH_SMALL(qt::k_lin_batch, h->M, B, (h->view(), dc, B, physical, drho, dbl, dst));
+  }
   if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;
   if (int r = fetch_out(h, dbl, bloch_out, nel, flags)) return r;
   if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
@@ -595,7 +626,11 @@ int qt_chol_param(qt_handle_t* h, const double* rho, int B, double* x, int32_t* 
   if (int r = stage_out(h, h->out0, x, nel, flags, &dx)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
   qt::PovmView pv{nullptr, nullptr, nullptr, 0, qt::ProductView{}};
-  QT_LAUNCH_SMALL_NOIMG(qt::k_chol_param, B, (pv, din, B, dx, dst));
+  if (h->nq >= 4) {
+    QT_LAUNCH_LARGE(qt::k_chol_param_large, B, 0, 1, (pv, din, B, dx, dst));
+  } else {
+    QT_LAUNCH_SMALL_NOIMG(qt::k_chol_param, B, (pv, din, B, dx, dst));
+  }
   if (int r = fetch_out(h, dx, x, nel, flags)) return r;
   if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
   if (int r = finish(h, flags)) return r;
@@ -612,7 +647,11 @@ int qt_chol_unparam(qt_handle_t* h, const double* x, int B, double* LLh, int fla
   if (int r = stage_in(h, h->in0, x, nel, flags, &din)) return r;
   if (int r = stage_out(h, h->out0, LLh, nel * 2, flags, &dout)) return r;
   qt::PovmView pv{nullptr, nullptr, nullptr, 0, qt::ProductView{}};
-  QT_LAUNCH_SMALL_NOIMG(qt::k_chol_unparam, B, (pv, din, B, dout));
+  if (h->nq >= 4) {
+    QT_LAUNCH_LARGE(qt::k_chol_unparam_large, B, 0, 1, (pv, din, B, dout));
+  } else {
+    QT_LAUNCH_SMALL_NOIMG(qt::k_chol_unparam, B, (pv, din, B, dout));
+  }
   if (int r = fetch_out(h, dout, LLh, nel * 2, flags)) return r;
   return finish(h, flags);
 }
@@ -630,7 +669,12 @@ int qt_nll_batch(qt_handle_t* h, const double* x, const int64_t* counts, int B, 
   if (int r = stage_in(h, h->in1, counts, (size_t)B * h->M, flags, &dc)) return r;
   if (int r = stage_out(h, h->out0, f, (size_t)B, flags, &df)) return r;
   if (int r = stage_out(h, h->out1, grad, nel, flags, &dg)) return r;
-  QT_LAUNCH_SMALL(qt::k_nll_batch, h->M, B, (h->view(), dx, dc, B, df, dg));
+  if (h->nq >= 4) {
+    if (int r = need_product(h, false)) return r;
+    QT_LAUNCH_LARGE(qt::k_nll_large, B, h->M, h->prod.R1, (h->view(), dx, dc, B, df, dg));
+  } else {
+    QT_LAUNCH_SMALL(qt::k_nll_batch, h->M, B, (h->view(), dx, dc, B, df, dg));
+  }
   if (int r = fetch_out(h, df, f, (size_t)B, flags)) return r;
   if (int r = fetch_out(h, dg, grad, nel, flags)) return r;
   return finish(h, flags);
@@ -654,16 +698,32 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
   if (int r = stage_out(h, h->out2, nfev, (size_t)B, flags, &dnfev)) return r;
   if (int r = stage_out(h, h->out3, fun, (size_t)B, flags, &dfun)) return r;
   if (int r = stage_out(h, h->out4, status, (size_t)B, flags, &dst)) return r;
-  HIPCHK(h->ws_x.ensure(nel * sizeof(double)));
-  HIPCHK(h->ws_g.ensure(nel * sizeof(double)));
-  HIPCHK(h->ws_f.ensure((size_t)B * sizeof(double)));
-  HIPCHK(h->ws_act.ensure((size_t)B * sizeof(int32_t)));
-  double *wx = h->ws_x.as<double>(), *wg = h->ws_g.as<double>(), *wf = h->ws_f.as<double>();
-  int32_t* wact = h->ws_act.as<int32_t>();
-  QT_LAUNCH_SMALL(qt::k_mle_start, h->M, B,
-                  (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
-  QT_LAUNCH_SMALL(qt::k_mle_bfgs, h->M, B,
-                  (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+  if (h->nq >= 4) {
+    if (int r = need_product(h, init == QT_INIT_LIN)) return r;
+    // the inverse Hessians live in HBM: D*D doubles per trial, processed in chunks of <= 4 GiB
+    const size_t per_trial = (size_t)h->D * h->D * sizeof(double);
+    int chunk = (int)(((size_t)4 << 30) / per_trial);
+    if (chunk > B) chunk = B;
+    HIPCHK(h->hess.ensure((size_t)chunk * per_trial));
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+      const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+      QT_LAUNCH_LARGE(qt::k_mle_large, nb, h->M, h->prod.R1,
+                      (h->view(), dc + (size_t)b0 * h->M, nb, init, max_iter, tol, drho + (size_t)b0 * h->D * 2,
+                       dnit ? dnit + b0 : nullptr, dnfev ? dnfev + b0 : nullptr, dfun ? dfun + b0 : nullptr,
+                       dst ? dst + b0 : nullptr, h->hess.as<double>()));
+    }
+  } else {
+    HIPCHK(h->ws_x.ensure(nel * sizeof(double)));
+    HIPCHK(h->ws_g.ensure(nel * sizeof(double)));
+    HIPCHK(h->ws_f.ensure((size_t)B * sizeof(double)));
+    HIPCHK(h->ws_act.ensure((size_t)B * sizeof(int32_t)));
+    double *wx = h->ws_x.as<double>(), *wg = h->ws_g.as<double>(), *wf = h->ws_f.as<double>();
+    int32_t* wact = h->ws_act.as<int32_t>();
+    QT_LAUNCH_SMALL(qt::k_mle_start, h->M, B,
+                    (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+    QT_LAUNCH_SMALL(qt::k_mle_bfgs, h->M, B,
+                    (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+  }
   if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;
   if (int r = fetch_out(h, dnit, nit, (size_t)B, flags)) return r;
   if (int r = fetch_out(h, dnfev, nfev, (size_t)B, flags)) return r;

@@ -1,0 +1,111 @@
+"""GPU: the workgroup-per-trial kernels for n = 4, 5 (csrc/qt_large.h) against the reference's
+golden vectors (tests/golden/large.npz: 'lin' and one NLL value, all the reference can afford at
+these sizes) and against the oracle's restatement of SciPy's BFGS for the MLE."""
+import numpy as np
+import pytest
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qp():
+    import quantpy_amd
+
+    return quantpy_amd
+
+
+def ginibre(rng, d, rank=None):
+    r = d if rank is None else rank
+    g = rng.standard_normal((d, r)) + 1j * rng.standard_normal((d, r))
+    rho = g @ g.conj().T
+    return rho / np.trace(rho)
+
+
+@pytest.mark.parametrize("n", [4, 5])
+def test_lin_and_nll_golden(qp, oracle, n):
+    g = load_golden("large")
+    a = qp.generate_measurement_matrix("proj-set", n)
+    counts = g[f"n{n}_counts"]
+    eng = qp.get_engine(n)
+    eng.set_povm(a, counts.sum(-1))
+    assert eng.product
+    rho_u, bloch = eng.lin(counts, physical=False, return_bloch=True)
+    assert np.abs(rho_u - g[f"n{n}_lin_unphys"]).max() < 1e-12
+    rho = eng.lin(counts)
+    assert np.abs(rho - g[f"n{n}_lin"]).max() < 1e-11
+    assert abs(oracle.infidelity(g[f"n{n}_lin"], rho)) < 1e-10
+    x, st = eng.chol_param(g[f"n{n}_lin"])
+    assert st == 0 and np.abs(x - g[f"n{n}_x"]).max() < 1e-9  # smallest pivots ~1e-8: conditioning, not error
+    assert np.abs(eng.chol_unparam(g[f"n{n}_x"]) - oracle.tril_vec_to_matrix(g[f"n{n}_x"])).max() < 1e-14
+    f, grad = eng.nll(g[f"n{n}_x"], counts)
+    assert abs(f - float(g[f"n{n}_nll"])) < 1e-11  # the reference's own _nll value
+    prob = oracle.NllProblem(counts, np.array(a))
+    xr = g[f"n{n}_x"] + 0.01 * np.random.default_rng(n).standard_normal(4**n)
+    fo, go = prob.nll_and_grad(xr)
+    f2, g2 = eng.nll(xr, counts)
+    assert abs(f2 - fo) < 1e-11 and np.abs(g2 - go).max() < 1e-9
+
+
+def test_lin_batch_edge_states_n4(qp, oracle):
+    """rank-1, maximally mixed and low-shot trials through the 16 x 16 Jacobi clip."""
+    n, d = 4, 16
+    a = qp.generate_measurement_matrix("proj-set", n)
+    ad = np.array(a)
+    rng = np.random.default_rng(8)
+    states = [ginibre(rng, d), ginibre(rng, d, rank=1), np.eye(d) / d]
+    eng = qp.get_engine(n)
+    for shots in (20000, 30):
+        np.random.seed(shots)
+        counts = np.stack([oracle.sample_counts(ad, oracle.bloch_from_matrix(s), shots) for s in states])
+        eng.set_povm(a, counts[0].sum(-1))
+        got = eng.lin(counts)
+        for c, r in zip(counts, got):
+            want = oracle.lin_estimate(c, ad)
+            assert np.abs(r - want).max() < 1e-11
+            assert abs(np.trace(r) - 1) < 1e-12 and np.linalg.eigvalsh(r).min() > 0
+
+
+@pytest.mark.parametrize("n,shots,nb", [(4, 300, 3), (4, 100000, 2), (5, 2000, 1)])
+def test_mle_vs_bfgs_restatement(qp, oracle, n, shots, nb):
+    d = 2**n
+    a = qp.generate_measurement_matrix("proj-set", n)
+    ad = np.array(a)
+    rng = np.random.default_rng(100 + n)
+    states = [ginibre(rng, d), ginibre(rng, d, rank=2)][:nb] + ([ginibre(rng, d, rank=1)] if nb > 2 else [])
+    np.random.seed(n * 7 + shots)
+    counts = np.stack([oracle.sample_counts(ad, oracle.bloch_from_matrix(s), shots) for s in states])
+    eng = qp.get_engine(n)
+    eng.set_povm(a, counts[0].sum(-1))
+    rho, info = eng.mle(counts, return_info=True)
+    for c, r, nit, st in zip(counts, rho, info["nit"], info["status"]):
+        ref, ri = oracle.mle_estimate(c, ad, return_info=True, solver="port")
+        assert st == 0 and ri["status"] == 0
+        assert nit == ri["nit"], (nit, ri["nit"])
+        assert abs(oracle.infidelity(ref, r)) < 1e-6
+    if n == 4:
+        rho_m, info_m = eng.mle(counts[:1], init="mixed", return_info=True)
+        ref, ri = oracle.mle_estimate(counts[0], ad, init="mixed", return_info=True, solver="port")
+        assert info_m["nit"][0] == ri["nit"] and abs(oracle.infidelity(ref, rho_m[0])) < 1e-6
+
+
+def test_dense_povm_refused_for_large_n(qp):
+    a = np.array(qp.generate_measurement_matrix("proj-set", 4))  # plain array: no factor
+    eng = qp.get_engine(4)
+    eng.set_povm(a, np.full(a.shape[0], 10))
+    assert not eng.product
+    with pytest.raises(qp.EngineError):
+        eng.lin(np.ones((1,) + a.shape[:2], dtype=np.int64))
+
+
+def test_state_tomograph_api_n4(qp, oracle):
+    rng = np.random.default_rng(44)
+    rho = ginibre(rng, 16)
+    np.random.seed(9)
+    t = qp.StateTomograph(qp.Qobj(rho))
+    t.experiment(50000, "proj-set")
+    lin = t.point_estimate("lin")
+    assert np.abs(lin.matrix - oracle.lin_estimate(t.results, np.array(t.povm_matrix))).max() < 1e-11
+    mle = t.point_estimate("mle")
+    ref, ri = oracle.mle_estimate(t.results, np.array(t.povm_matrix), return_info=True, solver="port")
+    assert t.mle_info["nit"] == ri["nit"] and abs(oracle.infidelity(ref, mle.matrix)) < 1e-6

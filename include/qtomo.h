@@ -55,7 +55,8 @@ int qt_version(void);
 const char* qt_last_error(void);
 /* number of HIP devices visible, or a negative qt_status */
 int qt_device_count(void);
-/* n_qubits in 1..5 for operator assembly and conversions; estimators: 1..3 in this release */
+/* n_qubits in 1..5.  Estimators: any POVM for n <= 3; n = 4, 5 need a product POVM
+ * (qt_set_povm_product).  Process tomography: n <= 2. */
 qt_handle_t* qt_create(int device, int n_qubits);
 void qt_destroy(qt_handle_t* h);
 int qt_sync(qt_handle_t* h);

@@ -11,87 +11,81 @@ from .operator import Operator, Z, _choi_to_kraus
 from .qobj import Qobj, fully_mixed
 from .routines import generate_single_entries, kron
 
-_SCALARS = (int, float, complex)
-
-
 class Channel(BaseQuantum):
-    """data : callable (needs `n_qubits`) | ndarray / Qobj (Choi matrix) | list (Kraus operators)."""
+    """A channel held in one or more of three forms: 'func' (map on states), 'choi', 'kraus'.
+
+    data : callable (needs `n_qubits`) | ndarray / Qobj (Choi matrix) | list of Kraus operators.
+    Missing forms are derived on first use and cached; assigning `.choi` / `.kraus` or calling
+    `set_func` makes that form the only valid one.
+    """
 
     def __init__(self, data, n_qubits=None):
-        self._types = set()
         if isinstance(data, self.__class__):
             self.__dict__ = deepcopy(data.__dict__)
             return
-        self._choi = self._func = self._kraus = None
+        self._forms = {}
         if callable(data):
             if n_qubits is None:
                 raise ValueError("`n_qubits` argument is compulsory when using init with function")
-            self._func = data
-            self.n_qubits = n_qubits
-            self._types.add("func")
+            self._define("func", data, n_qubits)
         elif isinstance(data, (np.ndarray, Qobj)):
-            self._choi = Qobj(data)
-            self.n_qubits = int(self._choi.n_qubits / 2)
-            self._types.add("choi")
+            choi = Qobj(data)
+            self._define("choi", choi, int(choi.n_qubits / 2))
         elif isinstance(data, list):
-            self._kraus = data
-            self.n_qubits = data[0].n_qubits
-            self._types.add("kraus")
+            self._define("kraus", data, data[0].n_qubits)
         else:
             raise ValueError("Invalid data format")
 
+    def _define(self, form, value, n_qubits):
+        self._forms = {form: value}
+        self.n_qubits = n_qubits
+
+    @property
+    def _types(self):  # the set of currently valid forms (name kept from the reference)
+        return set(self._forms)
+
     def set_func(self, data, n_qubits):
         """Redefine the channel by a map on states."""
-        self._types = {"func"}
-        self._func = data
-        self.n_qubits = n_qubits
+        self._define("func", data, n_qubits)
 
     # ---- representations ----------------------------------------------------------------------
     @property
     def choi(self):
         """sum_ij E_ij (x) channel(E_ij), built on first use from whichever form is available."""
-        if "choi" not in self._types:
+        if "choi" not in self._forms:
             dim = 2**self.n_qubits
             acc = Qobj(np.zeros((dim * dim, dim * dim), dtype=np.complex128))
             for unit in generate_single_entries(dim):
                 acc += kron(Qobj(unit), self.transform(unit))
-            self._choi = acc
-            self._types.add("choi")
-        return self._choi
+            self._forms["choi"] = acc
+        return self._forms["choi"]
 
     @choi.setter
     def choi(self, data):
         if not isinstance(data, Qobj):
             data = Qobj(data)
-        elif not isinstance(data, np.ndarray):
-            raise ValueError("Invalid data format")
-        self._types = {"choi"}
-        self._choi = data
-        self.n_qubits = int(np.log2(data.shape[0]) / 2)
+        self._define("choi", data, int(data.n_qubits / 2))
 
     @property
     def kraus(self):
-        if "kraus" not in self._types:
-            self._kraus = _choi_to_kraus(self.choi)
-            self._types.add("kraus")
-        return self._kraus
+        if "kraus" not in self._forms:
+            self._forms["kraus"] = _choi_to_kraus(self.choi)
+        return self._forms["kraus"]
 
     @kraus.setter
     def kraus(self, data):
         if not isinstance(data, list):
             raise ValueError("Invalid data format")
-        self._types = {"kraus"}
-        self._kraus = data
-        self.n_qubits = data[0].n_qubits
+        self._define("kraus", data, data[0].n_qubits)
 
     def transform(self, state):
-        """Apply the channel to a state (Qobj or array)."""
+        """Apply the channel to a state (Qobj or array); Kraus form first, then the map, then Choi."""
         if not isinstance(state, Qobj):
             state = Qobj(state)
-        if "kraus" in self._types:
-            return np.sum([op.transform(state) for op in self.kraus])
-        if "func" in self._types:
-            return self._func(state)
+        if "kraus" in self._forms:
+            return np.sum([op.transform(state) for op in self._forms["kraus"]])
+        if "func" in self._forms:
+            return self._forms["func"](state)
         # Choi form: Tr_in[(rho^T (x) I) C]
         lifted = kron(state.T, Qobj(np.eye(2**self.n_qubits)))
         return (lifted @ self.choi).ptrace(list(range(self.n_qubits, 2 * self.n_qubits)))
@@ -99,78 +93,29 @@ class Channel(BaseQuantum):
     def is_cptp(self, atol=1e-5, verbose=True):
         """Trace preservation (Tr_out C = I) and complete positivity (C >= 0) within `atol`."""
         reduced = self.choi.ptrace(list(range(self.n_qubits)))
-        tp = np.allclose(reduced.matrix, np.eye(2**reduced.n_qubits), atol=atol)
-        cp = np.allclose(np.minimum(np.real(self.choi.eig()[0]), 0), 0, atol=atol)
-        if verbose and not tp:
-            print("Not trace-preserving", file=sys.stderr)
-        if verbose and not cp:
-            print("Not completely positive", file=sys.stderr)
-        return tp and cp
+        checks = (
+            (np.allclose(reduced.matrix, np.eye(2**reduced.n_qubits), atol=atol), "Not trace-preserving"),
+            (np.allclose(np.minimum(np.real(self.choi.eig()[0]), 0), 0, atol=atol), "Not completely positive"),
+        )
+        for passed, text in checks:
+            if verbose and not passed:
+                print(text, file=sys.stderr)
+        return all(passed for passed, _ in checks)
 
-    # ---- arithmetic acts on the Choi matrix -----------------------------------------------------
-    @property
-    def T(self):
-        return self.__class__(self.choi.T)
+    # ---- arithmetic: inherited from BaseQuantum, acting on the Choi matrix -------------------------
+    _payload_name = "choi"
 
-    @property
-    def H(self):
-        return self.__class__(self.choi.H)
+    def kron(self, other):
+        raise NotImplementedError("Kronecker products of channels are not defined in quantpy")
 
-    def conj(self):
-        return self.__class__(self.choi.conj())
+    def __matmul__(self, other):
+        raise NotImplementedError("composition of channels is not defined in quantpy")
 
     def __repr__(self):
         return "Quantum channel with Choi matrix\n" + repr(self.choi.matrix)
 
     def _repr_latex_(self):
         return r"Choi matrix: " + Qobj(self.choi.matrix)._repr_latex_()
-
-    def __eq__(self, other):
-        return np.array_equal(self.choi.matrix, other.choi.matrix)
-
-    def __ne__(self, other):
-        return not np.array_equal(self.choi.matrix, other.choi.matrix)
-
-    def __neg__(self):
-        return self.__class__(-self.choi)
-
-    def __add__(self, other):
-        return self.__class__(self.choi + other.choi)
-
-    def __sub__(self, other):
-        return self.__class__(self.choi - other.choi)
-
-    def __mul__(self, other):
-        if not isinstance(other, _SCALARS):
-            raise ValueError("Only multiplication by a scalar is allowed")
-        return self.__class__(self.choi * other)
-
-    __rmul__ = __mul__
-
-    def __truediv__(self, other):
-        if not isinstance(other, _SCALARS):
-            raise ValueError("Only division by a scalar is allowed")
-        return self.__class__(self.choi / other)
-
-    def __iadd__(self, other):
-        self.choi = self.choi + other.choi
-        return self
-
-    def __isub__(self, other):
-        self.choi = self.choi - other.choi
-        return self
-
-    def __imul__(self, other):
-        if type(other) not in _SCALARS:
-            raise ValueError("Only multiplication by a scalar is supported")
-        self.choi = self.choi * other
-        return self
-
-    def __idiv__(self, other):
-        if type(other) not in _SCALARS:
-            raise ValueError("Only division by a scalar is supported")
-        self.choi = self.choi / other
-        return self
 
 
 # ---- channel library --------------------------------------------------------------------------------

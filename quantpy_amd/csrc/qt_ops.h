@@ -95,60 +95,58 @@ __global__ void k_transpose(const double* __restrict__ in, int R, int C, double*
   }
 }
 
-// ---- generic tiled GEMM  C[MxN] = op(A) op(B), real (CPLX = 0) or complex (CPLX = 1) ---------
-// Row-major operands with explicit strides; TA / TB = plain transposes (never conjugated:
-// routines.py:71 uses A.T).  16x16 output tile per 256-thread block, K staged through LDS.
+// ---- GEMM  C[MxN] = op(A) op(B) on the FP64 matrix cores, real (CPLX = 0) or complex (CPLX = 1) ----
+// The one true GEMM of the path: the Gram matrix A^T A and the product inv(A^T A) A^T of the left
+// inverse (routines.py:69-71) -- 256 x 256 x 576 complex for the C3 process design matrix
+// (process.py:208-210), 64 x 64 x 216 real for the C2 POVM.  Row-major operands with explicit leading
+// dimensions; TA / TB select PLAIN transposes (never conjugated: routines.py:71 uses A.T, and the
+// design matrix is complex).  One wavefront owns one 16 x 16 tile of C and walks K four at a time with
+// v_mfma_f64_16x16x4_f64: lane l feeds A[row0 + l%16][k0 + l/16] and B[k0 + l/16][col0 + l%16] and
+// holds C[row0 + l/16 + 4 r][col0 + l%16], r = 0..3.  Complex = four real products into four
+// accumulator tiles (rr, ii, ri, ir).  Edges are zero-padded by predicated loads.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
 template <int CPLX>
-__global__ void __launch_bounds__(256) k_gemm(int M, int N, int K, const double* __restrict__ A, int lda, int ta,
-                                              const double* __restrict__ B, int ldb, int tb, double* __restrict__ C,
-                                              int ldc) {
-  constexpr int TS = 16;
+__global__ void __launch_bounds__(64) k_gemm(int M, int N, int K, const double* __restrict__ A, int lda, int ta,
+                                             const double* __restrict__ B, int ldb, int tb, double* __restrict__ C,
+                                             int ldc) {
   constexpr int W = CPLX ? 2 : 1;
-  __shared__ double sa[TS][TS + 1][W];
-  __shared__ double sb[TS][TS + 1][W];
-  const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
-  const int row = blockIdx.y * TS + ty, col = blockIdx.x * TS + tx;
-  double accr = 0.0, acci = 0.0;
-  for (int k0 = 0; k0 < K; k0 += TS) {
-    {
-      const int ar = blockIdx.y * TS + ty, ak = k0 + tx;  // sa[ty][tx] = opA[ar][ak]
-      double vr = 0.0, vi = 0.0;
-      if (ar < M && ak < K) {
-        const size_t idx = ta ? ((size_t)ak * lda + ar) : ((size_t)ar * lda + ak);
-        vr = A[idx * W];
-        if (CPLX) vi = A[idx * W + 1];
-      }
-      sa[ty][tx][0] = vr;
-      if (CPLX) sa[ty][tx][W - 1] = vi;
-      const int bk = k0 + ty, bc = blockIdx.x * TS + tx;  // sb[ty][tx] = opB[bk][bc]
-      vr = 0.0;
-      vi = 0.0;
-      if (bk < K && bc < N) {
-        const size_t idx = tb ? ((size_t)bc * ldb + bk) : ((size_t)bk * ldb + bc);
-        vr = B[idx * W];
-        if (CPLX) vi = B[idx * W + 1];
-      }
-      sb[ty][tx][0] = vr;
-      if (CPLX) sb[ty][tx][W - 1] = vi;
+  const int lane = threadIdx.x;
+  const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;
+  const int ar = row0 + (lane & 15), bc = col0 + (lane & 15), kk = lane >> 4;
+  v4f64 acc_rr = {0.0, 0.0, 0.0, 0.0}, acc_ii = acc_rr, acc_ri = acc_rr, acc_ir = acc_rr;
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int k = k0 + kk;
+    double a_re = 0.0, a_im = 0.0, b_re = 0.0, b_im = 0.0;
+    if (ar < M && k < K) {
+      const size_t idx = ta ? ((size_t)k * lda + ar) : ((size_t)ar * lda + k);
+      a_re = A[idx * W];
+      if (CPLX) a_im = A[idx * W + 1];
     }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < TS; ++kk) {
-      const double ar_ = sa[ty][kk][0], br_ = sb[kk][tx][0];
-      if (CPLX) {
-        const double ai_ = sa[ty][kk][W - 1], bi_ = sb[kk][tx][W - 1];
-        accr += ar_ * br_ - ai_ * bi_;
-        acci += ar_ * bi_ + ai_ * br_;
-      } else {
-        accr += ar_ * br_;
-      }
+    if (k < K && bc < N) {
+      const size_t idx = tb ? ((size_t)bc * ldb + k) : ((size_t)k * ldb + bc);
+      b_re = B[idx * W];
+      if (CPLX) b_im = B[idx * W + 1];
     }
-    __syncthreads();
+    acc_rr = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re, b_re, acc_rr, 0, 0, 0);
+    if (CPLX) {
+      acc_ii = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im, b_im, acc_ii, 0, 0, 0);
+      acc_ri = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re, b_im, acc_ri, 0, 0, 0);
+      acc_ir = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im, b_re, acc_ir, 0, 0, 0);
+    }
   }
-  if (row < M && col < N) {
-    const size_t idx = (size_t)row * ldc + col;
-    C[idx * W] = accr;
-    if (CPLX) C[idx * W + 1] = acci;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + (lane >> 4) + 4 * r, col = col0 + (lane & 15);
+    if (row < M && col < N) {
+      const size_t idx = (size_t)row * ldc + col;
+      if (CPLX) {
+        C[idx * W] = acc_rr[r] - acc_ii[r];
+        C[idx * W + 1] = acc_ri[r] + acc_ir[r];
+      } else {
+        C[idx] = acc_rr[r];
+      }
+    }
   }
 }
 

@@ -366,11 +366,11 @@ static int finish_set_povm(qt_handle_t* h, int S, int K) {
                      dAw, dAwT);
   // Gram = A'^T A' into the left half of [G | I]
   dim3 gg((D + 15) / 16, (D + 15) / 16);
-  hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(256), 0, h->stream, D, D, (int)M, dAw, D, 1, dAw, D, 0, aug, 2 * D);
+  hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(64), 0, h->stream, D, D, (int)M, dAw, D, 1, dAw, D, 0, aug, 2 * D);
   hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, D, aug, h->info.as<int>());
   // left inverse = inv(G) A'^T   (D x M)
   dim3 gp(((int)M + 15) / 16, (D + 15) / 16);
-  hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(256), 0, h->stream, D, (int)M, D, aug + D, 2 * D, 0, dAwT, (int)M, 0, dP,
+  hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(64), 0, h->stream, D, (int)M, D, aug + D, 2 * D, 0, dAwT, (int)M, 0, dP,
                      (int)M);
   hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dP, D, (int)M, dPT);
   int info = 0;
@@ -449,9 +449,9 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
   HIPCHK(h->pr_aug.ensure((size_t)4 * 8 * sizeof(double)));
   {
     double *T = h->pr_T.as<double>(), *g = h->pr_aug.as<double>(), *P1 = h->pr_P1.as<double>();
-    hipLaunchKernelGGL(qt::k_gemm<0>, dim3(1, 1), dim3(256), 0, h->stream, 4, 4, R1, T, 4, 1, T, 4, 0, g, 8);
+    hipLaunchKernelGGL(qt::k_gemm<0>, dim3(1, 1), dim3(64), 0, h->stream, 4, 4, R1, T, 4, 1, T, 4, 0, g, 8);
     hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, 4, g, h->info.as<int>());
-    hipLaunchKernelGGL(qt::k_gemm<0>, dim3((R1 + 15) / 16, 1), dim3(256), 0, h->stream, 4, R1, 4, g + 4, 8, 0, T, 4, 1, P1,
+    hipLaunchKernelGGL(qt::k_gemm<0>, dim3((R1 + 15) / 16, 1), dim3(64), 0, h->stream, 4, R1, 4, g + 4, 8, 0, T, 4, 1, P1,
                        R1);
     hipLaunchKernelGGL(qt::k_transpose, dim3(1), dim3(256), 0, h->stream, P1, 4, R1, h->pr_P1T.as<double>());
   }
@@ -764,14 +764,14 @@ int qt_left_inverse(qt_handle_t* h, const double* A, int rows, int cols, int is_
   double* g = aug.as<double>();
   dim3 gg((cols + 15) / 16, (cols + 15) / 16), gp((rows + 15) / 16, (cols + 15) / 16);
   if (is_complex) {
-    hipLaunchKernelGGL(qt::k_gemm<1>, gg, dim3(256), 0, h->stream, cols, cols, rows, dA, cols, 1, dA, cols, 0, g, 2 * cols);
+    hipLaunchKernelGGL(qt::k_gemm<1>, gg, dim3(64), 0, h->stream, cols, cols, rows, dA, cols, 1, dA, cols, 0, g, 2 * cols);
     hipLaunchKernelGGL(qt::k_gauss_jordan<1>, dim3(1), dim3(1024), 0, h->stream, cols, g, h->info.as<int>());
-    hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(256), 0, h->stream, cols, rows, cols, g + (size_t)cols * 2, 2 * cols, 0, dA,
+    hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(64), 0, h->stream, cols, rows, cols, g + (size_t)cols * 2, 2 * cols, 0, dA,
                        cols, 1, dout, rows);
   } else {
-    hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(256), 0, h->stream, cols, cols, rows, dA, cols, 1, dA, cols, 0, g, 2 * cols);
+    hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(64), 0, h->stream, cols, cols, rows, dA, cols, 1, dA, cols, 0, g, 2 * cols);
     hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, cols, g, h->info.as<int>());
-    hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(256), 0, h->stream, cols, rows, cols, g + cols, 2 * cols, 0, dA, cols, 1,
+    hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(64), 0, h->stream, cols, rows, cols, g + cols, 2 * cols, 0, dA, cols, 1,
                        dout, rows);
   }
   int info = 0;
@@ -811,9 +811,9 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
                      (const double*)ps.emats, lifp);
   const int c2 = (int)C2, rr = (int)R;
   dim3 gg((c2 + 15) / 16, (c2 + 15) / 16), gp((rr + 15) / 16, (c2 + 15) / 16);
-  hipLaunchKernelGGL(qt::k_gemm<1>, gg, dim3(256), 0, h->stream, c2, c2, rr, lifp, c2, 1, lifp, c2, 0, aug, 2 * c2);
+  hipLaunchKernelGGL(qt::k_gemm<1>, gg, dim3(64), 0, h->stream, c2, c2, rr, lifp, c2, 1, lifp, c2, 0, aug, 2 * c2);
   hipLaunchKernelGGL(qt::k_gauss_jordan<1>, dim3(1), dim3(1024), 0, h->stream, c2, aug, h->info.as<int>());
-  hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(256), 0, h->stream, c2, rr, c2, aug + (size_t)c2 * 2, 2 * c2, 0, lifp, c2, 1,
+  hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(64), 0, h->stream, c2, rr, c2, aug + (size_t)c2 * 2, 2 * c2, 0, lifp, c2, 1,
                      pinv, rr);
   hipLaunchKernelGGL(qt::k_transpose_c, dim3(grid_for(R * C2)), dim3(256), 0, h->stream, pinv, c2, rr, pinvT);
   int info = 0;

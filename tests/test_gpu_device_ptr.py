@@ -1,0 +1,92 @@
+"""GPU: device-pointer (QT_DEVICE_PTR) calls on torch CUDA tensors -- the form bench.py and any
+GPU-resident caller use -- give the same results as the host-pointer calls; stream hand-over."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_pointer_calls_match_host_calls(oracle):
+    import torch
+
+    import quantpy_amd as qp
+
+    rng = np.random.default_rng(5)
+    n, d, B = 3, 8, 37
+    a = qp.generate_measurement_matrix("proj-set", n)
+    g = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    rho = g @ g.conj().T
+    rho /= np.trace(rho)
+    np.random.seed(1)
+    counts = np.stack([oracle.sample_counts(np.array(a), oracle.bloch_from_matrix(rho), 700) for _ in range(B)])
+    eng = qp.get_engine(n)
+    eng.set_povm(a, counts[0].sum(-1))
+    host_lin = eng.lin(counts)
+    host_mle, info = eng.mle(counts, return_info=True)
+    host_dist = eng.hs_dist(host_mle, rho)
+
+    cd = torch.from_numpy(counts).cuda()
+    rho_d = torch.empty((B, d, d), dtype=torch.complex128, device="cuda")
+    nit = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    eng.lin_dev(cd, rho_d)
+    eng.sync()
+    assert np.array_equal(rho_d.cpu().numpy(), host_lin)
+    eng.mle_dev(cd, rho_d, nit=nit, status=st)
+    dist_d = torch.empty(B, dtype=torch.float64, device="cuda")
+    eng.hs_dist_dev(rho_d, torch.from_numpy(rho).cuda(), dist_d)
+    eng.sync()
+    assert np.array_equal(rho_d.cpu().numpy(), host_mle)  # same kernels, same inputs: bit-identical
+    assert np.array_equal(nit.cpu().numpy(), info["nit"]) and np.all(st.cpu().numpy() == 0)
+    assert np.array_equal(dist_d.cpu().numpy(), host_dist)
+
+    # run on a torch stream (a NULL handle means "engine's own stream", so use a side stream),
+    # then give the engine its own stream back
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.set_stream(side.cuda_stream)
+        rho_d.zero_()
+        eng.mle_dev(cd, rho_d)  # ordered after zero_() on the same stream
+    side.synchronize()
+    assert np.array_equal(rho_d.cpu().numpy(), host_mle)
+    eng.set_stream(0)
+    eng.timer_begin()
+    eng.mle_dev(cd, rho_d)
+    assert eng.timer_end() > 0
+
+
+def test_born_probs_device_and_batch_shapes(oracle):
+    import torch
+
+    import quantpy_amd as qp
+
+    eng = qp.get_engine(2)
+    a = qp.generate_measurement_matrix("sic", 2)
+    eng.set_povm(a, np.ones(1))
+    rng = np.random.default_rng(0)
+    bl = rng.standard_normal((19, 16)) * 0.05
+    bl[:, 0] = 0.25
+    want = np.stack([oracle.born_probs(np.array(a), b) for b in bl])
+    out = torch.empty((19, 1, 16), dtype=torch.float64, device="cuda")
+    eng.born_probs(torch.from_numpy(bl).cuda(), out=out)
+    eng.sync()
+    assert np.abs(out.cpu().numpy() - want).max() < 1e-14
+    assert np.abs(eng.born_probs(bl[3]) - want[3]).max() < 1e-14
+
+
+def test_error_codes_not_exceptions_across_the_abi():
+    import quantpy_amd as qp
+    from quantpy_amd import _capi
+
+    eng = qp.Engine(1)
+    with pytest.raises(qp.EngineError) as ei:  # estimator before set_povm
+        eng.lib.qt_lin_batch.restype  # noqa: B018
+        eng._chk(eng.lib.qt_lin_batch(eng._h, None, 1, 1, None, None, None, 0))
+    assert ei.value.code in (_capi.QT_ERR_STATE, _capi.QT_ERR_ARG)
+    with pytest.raises(qp.EngineError) as ei:
+        eng.set_povm(np.ones((1, 3, 4)) / 3, np.ones(1))  # 3 rows < D = 4: not informationally complete
+    assert ei.value.code == _capi.QT_ERR_SINGULAR
+    with pytest.raises(qp.EngineError) as ei:
+        eng.set_povm(np.tile(np.array([[0.5, 0.5, 0, 0], [0.5, -0.5, 0, 0]]), (3, 1, 1)), np.ones(3))  # only X
+    assert ei.value.code == _capi.QT_ERR_SINGULAR
+    eng.close()

@@ -16,6 +16,11 @@ from .measurements import generate_measurement_matrix  # noqa: F401
 from .operator import Operator  # noqa: F401
 from .qobj import Qobj  # noqa: F401
 from .routines import generate_pauli, join_gates, kron  # noqa: F401
-from .tomography.interval import BootstrapProcessInterval, BootstrapStateInterval, ConfidenceInterval  # noqa: F401
+from .tomography.interval import (  # noqa: F401
+    BootstrapProcessInterval,
+    BootstrapStateInterval,
+    ConfidenceInterval,
+    MomentInterval,
+)
 from .tomography.process import ProcessTomograph  # noqa: F401
 from .tomography.state import StateTomograph  # noqa: F401

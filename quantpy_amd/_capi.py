@@ -64,6 +64,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own HSA/HIP runtime.  If libqtomo.so (linked against the system
+    # ROCm) initialises the GPU first and torch is imported afterwards, the process ends up with two
+    # HSA runtimes and torch reports "No HIP GPUs are available"; the other order works (the loader
+    # shares the HSA runtime by soname).  So when torch is installed, let it load first.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise EngineUnavailable(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

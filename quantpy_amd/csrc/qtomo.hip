@@ -67,7 +67,7 @@ struct qt_handle {
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // POVM cache
-  bool povm_set = false;
+  bool povm_set = false, pinv_ready = false;
   int S = 0, K = 0, M = 0;
   DevBuf A, AT, Aw, AwT, Pinv, PinvT, Ns, aug, info;
   // product-POVM (Kronecker) description, valid when prod.enabled
@@ -355,32 +355,45 @@ int qt_povm_kron(qt_handle_t* h, const double* povm1, int S1, int K1, double* ou
   return finish(h, flags);
 }
 
-// Shared tail of qt_set_povm / qt_set_povm_product: h->A ([M][D]) and h->Ns ([S]) are on the device.
-static int finish_set_povm(qt_handle_t* h, int S, int K) {
-  const int D = h->D;
-  const size_t M = (size_t)S * K;
-  double *dA = h->A.as<double>(), *dAT = h->AT.as<double>(), *dAw = h->Aw.as<double>(), *dAwT = h->AwT.as<double>();
+// Dense left inverse inv(A'^T A') A'^T of the cached weighted POVM (Gram GEMM, pivoted Gauss-Jordan, GEMM).
+static int compute_dense_pinv(qt_handle_t* h) {
+  const int D = h->D, M = h->M;
+  double *dAw = h->Aw.as<double>(), *dAwT = h->AwT.as<double>();
   double *dP = h->Pinv.as<double>(), *dPT = h->PinvT.as<double>(), *aug = h->aug.as<double>();
-  hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dA, (int)M, D, dAT);
-  hipLaunchKernelGGL(qt::k_weight_povm, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dA, h->Ns.as<double>(), S, K, D,
-                     dAw, dAwT);
-  // Gram = A'^T A' into the left half of [G | I]
   dim3 gg((D + 15) / 16, (D + 15) / 16);
-  hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(64), 0, h->stream, D, D, (int)M, dAw, D, 1, dAw, D, 0, aug, 2 * D);
+  hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(64), 0, h->stream, D, D, M, dAw, D, 1, dAw, D, 0, aug, 2 * D);
   hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, D, aug, h->info.as<int>());
-  // left inverse = inv(G) A'^T   (D x M)
-  dim3 gp(((int)M + 15) / 16, (D + 15) / 16);
-  hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(64), 0, h->stream, D, (int)M, D, aug + D, 2 * D, 0, dAwT, (int)M, 0, dP,
-                     (int)M);
-  hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dP, D, (int)M, dPT);
+  dim3 gp((M + 15) / 16, (D + 15) / 16);
+  hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(64), 0, h->stream, D, M, D, aug + D, 2 * D, 0, dAwT, M, 0, dP, M);
+  hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for((size_t)M * D)), dim3(256), 0, h->stream, dP, D, M, dPT);
   int info = 0;
   HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   if (info != 0) return fail(QT_ERR_SINGULAR, "A^T A is singular (no pivot in column %d): POVM not informationally complete", info - 1);
+  h->pinv_ready = true;
+  return 0;
+}
+
+// Shared tail of qt_set_povm / qt_set_povm_product: h->A ([M][D]) and h->Ns ([S]) are on the device.
+// `dense_pinv`: build the dense left inverse now (a factorised POVM with equal shots never reads it:
+// it is then built on demand by qt_get_left_inverse -- at n = 5 that is 0.75 s of set-up saved).
+static int finish_set_povm(qt_handle_t* h, int S, int K, bool dense_pinv) {
+  const int D = h->D;
+  const size_t M = (size_t)S * K;
+  double *dA = h->A.as<double>(), *dAT = h->AT.as<double>(), *dAw = h->Aw.as<double>(), *dAwT = h->AwT.as<double>();
+  hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dA, (int)M, D, dAT);
+  hipLaunchKernelGGL(qt::k_weight_povm, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dA, h->Ns.as<double>(), S, K, D,
+                     dAw, dAwT);
   h->S = S;
   h->K = K;
   h->M = (int)M;
+  h->pinv_ready = false;
+  if (dense_pinv) {
+    if (int r = compute_dense_pinv(h)) return r;
+  } else {
+    HIPCHK(hipGetLastError());
+  }
   h->povm_set = true;
   return 0;
 }
@@ -412,7 +425,7 @@ int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns,
   const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   HIPCHK(hipMemcpyAsync(h->A.p, A, (size_t)S * K * h->D * sizeof(double), kind, h->stream));
   HIPCHK(hipMemcpyAsync(h->Ns.p, Ns, S * sizeof(double), kind, h->stream));
-  return finish_set_povm(h, S, K);
+  return finish_set_povm(h, S, K, true);
 }
 
 int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, const double* Ns, int flags) {
@@ -442,7 +455,10 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
   // full tensor (Born kernel, dense fallbacks, process tomography) -- a2, same kernel as qt_povm_kron
   hipLaunchKernelGGL(qt::k_povm_kron, dim3(grid_for((size_t)M * D)), dim3(256), 0, h->stream, n, h->pr_T.as<double>(), S1,
                      K1, h->A.as<double>());
-  if (int r = finish_set_povm(h, (int)S, (int)K)) return r;
+  bool uniform_shots = true;
+  for (long long s_ = 1; s_ < S; ++s_)
+    if (ns[s_] != ns[0]) uniform_shots = false;
+  if (int r = finish_set_povm(h, (int)S, (int)K, !uniform_shots)) return r;
   // pinv of the one-qubit table, on the device: inv(T^T T) T^T  ([4][R1]) and its transpose
   HIPCHK(h->pr_P1.ensure((size_t)4 * R1 * sizeof(double)));
   HIPCHK(h->pr_P1T.ensure((size_t)4 * R1 * sizeof(double)));
@@ -526,6 +542,8 @@ int qt_get_left_inverse(qt_handle_t* h, double* out, int flags) {
   if (int r = check_handle(h)) return r;
   if (int r = need_povm(h)) return r;
   if (!out) return fail(QT_ERR_ARG, "null out");
+  if (!h->pinv_ready)
+    if (int r = compute_dense_pinv(h)) return r;
   const size_t bytes = (size_t)h->D * h->M * sizeof(double);
   HIPCHK(hipMemcpyAsync(out, h->Pinv.p, bytes, (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                         h->stream));

@@ -1,3 +1,8 @@
-from .interval import BootstrapProcessInterval, BootstrapStateInterval, ConfidenceInterval  # noqa: F401
+from .interval import (  # noqa: F401
+    BootstrapProcessInterval,
+    BootstrapStateInterval,
+    ConfidenceInterval,
+    MomentInterval,
+)
 from .process import ProcessTomograph  # noqa: F401
 from .state import StateTomograph  # noqa: F401

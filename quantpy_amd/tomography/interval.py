@@ -5,8 +5,15 @@ the loop only draws the counts (host RNG, same call order, so a seed gives the s
 all resamples are then reconstructed in one batched launch, sharded over the ranks of the
 process group when there is one, and the distances are all-gathered (quantpy_amd.distributed).
 
-The closed-form / convex-programming intervals of the reference (Moment*, Sugiyama, Polytope*,
-Holder, MHMC*) are outside this package's hot path and are not provided.
+`MomentInterval` (reference interval.py:59-110 with stats.py:21-47) is the closed-form interval the
+reference's CLI scripts use: the first two moments of the squared Hilbert-Schmidt error of the
+linear-inversion estimate under multinomial noise, matched to a gamma / normal / exponential
+law.  Its one heavy step, the left inverse of the (state or process) design matrix, runs on the GPU
+(qt_left_inverse); the moment sums are O(M^2) host arithmetic, written in matrix form instead of the
+reference's six-operand einsums.
+
+The convex-programming / MCMC intervals of the reference (MomentFidelity*, Sugiyama, Polytope*,
+Holder, MHMC*) need cvxopt or serial chains and are not provided.
 """
 from abc import ABC, abstractmethod
 from enum import Enum, auto
@@ -14,9 +21,12 @@ from enum import Enum, auto
 import numpy as np
 from scipy.interpolate import interp1d
 
+import scipy.stats as sts
+
 from .. import distributed as qdist
 from ..engine import get_engine
-from ..geometry import hs_dst
+from ..geometry import hs_dst, trace_dst
+from ..routines import _left_inv
 
 
 class Mode(Enum):
@@ -58,6 +68,74 @@ class ConfidenceInterval(ABC):
     def _finish(self, dist):
         dist = np.sort(dist)
         self.cl_to_dist = interp1d(np.linspace(0, 1, len(dist)), dist)
+
+
+def l2_moments(freq, n_trials, inv_matrix):
+    """Mean and variance of ||W^(1/2)(f - p)||^2 for multinomial frequencies `freq` (S, K) with
+    `n_trials` shots per setting and W = P^T P, P = `inv_matrix` reshaped (D, S*K)
+    (reference stats.py:5-47: l2_mean / l2_variance with weights einsum('aij,akl->ijkl', P, P)).
+    With Q_ab = f_a^T W_ab f_b, t_a = sum_i W_aa[i,i] f_ai and U[a, (b,j)] = sum_i f_ai W[(a,i),(b,j)]:
+        E   = (sum t - tr Q) / N
+        E_2 = ((tr Q - sum t)^2 + 2 sum_ab Q_ab^2 - 4 sum_a sum_bj U[a,bj]^2 f_bj + 2 f^T (W o W) f) / N^2
+    which is the reference's twelve einsum terms collected."""
+    s, k = freq.shape
+    p = inv_matrix.reshape(inv_matrix.shape[0], s * k)
+    w = p.T @ p  # (M, M), symmetric
+    f = freq.reshape(-1)
+    w4 = w.reshape(s, k, s, k)
+    u = np.einsum("ai,aibj->abj", freq, w4)  # U[a, b, j]
+    q = np.einsum("abj,bj->ab", u, freq)
+    t = np.einsum("aiai,ai->", w4, freq)
+    tr_q = np.trace(q)
+    first = (t - tr_q) / n_trials
+    second = ((tr_q - t) ** 2 + 2 * np.sum(q * q) - 4 * np.einsum("abj,abj,bj->", u, u, freq)
+              + 2 * f @ (w * w) @ f) / n_trials**2
+    return first, second - first**2
+
+
+class MomentInterval(ConfidenceInterval):
+    """Closed-form interval from the first two moments of the squared HS error of linear inversion.
+    distr_type : 'gamma' (default) | 'norm' | 'exp'."""
+
+    def __init__(self, tmg, distr_type="gamma"):
+        super().__init__(tmg, **_pop_hidden_keys(locals()))
+
+    def setup(self):
+        tmg = self.tmg
+        if self.mode == Mode.STATE:
+            dim = 2**tmg.state.n_qubits
+            n_measurements = tmg.n_measurements
+            frequencies = tmg.results / tmg.n_measurements[:, None]
+            povm = np.asarray(tmg.povm_matrix)
+            design = povm.reshape(-1, povm.shape[-1])
+        else:
+            dim = 4**tmg.channel.n_qubits
+            first = tmg.tomographs[0]
+            n_measurements = first.n_measurements
+            frequencies = np.vstack([t.results / n_measurements[:, None] for t in tmg.tomographs])
+            povm = np.asarray(first.povm_matrix)
+            povm_rows = povm.reshape(-1, povm.shape[-1])
+            states = np.asarray([rho.T.bloch for rho in tmg.input_basis.elements])
+            design = np.einsum("sd,pi->spdi", states, povm_rows).reshape(states.shape[0] * povm_rows.shape[0], -1)
+        inv_matrix = _left_inv(design) / dim  # GPU: Gram GEMM (MFMA), pivoted Gauss-Jordan, GEMM
+        mean, variance = l2_moments(frequencies, n_measurements[0], np.asarray(inv_matrix))
+        if self.distr_type == "norm":
+            distr = sts.norm(loc=mean, scale=np.sqrt(variance))
+        elif self.distr_type == "gamma":
+            scale = variance / mean
+            distr = sts.gamma(a=mean / scale, scale=scale)
+        elif self.distr_type == "exp":
+            distr = sts.expon(scale=mean)
+        else:
+            raise NotImplementedError(f"Unsupported distribution type {self.distr_type}")
+        if tmg.dst == hs_dst:
+            alpha = np.sqrt(dim / 2)
+        elif tmg.dst == trace_dst:
+            alpha = dim / 2
+        else:
+            raise NotImplementedError()
+        self.mean, self.variance = mean, variance
+        self.cl_to_dist = lambda cl: np.sqrt(distr.ppf(cl)) * alpha
 
 
 class BootstrapStateInterval(ConfidenceInterval):

@@ -1,0 +1,10 @@
+#!/usr/bin/env python3
+"""JSON counts -> process estimate + HS confidence radii (same interface as the reference's script)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quantpy_amd.cli import process_interval  # noqa: E402
+
+if __name__ == "__main__":
+    process_interval()

@@ -415,10 +415,57 @@ def gen_process():
             out[key + "_lifp_oper_abs_sum"] = np.array(np.abs(tmg._lifp_oper).sum())
         out[key + "_dykstra_iters"] = np.array(dyk_iters(tmg, _mat2vec(ch.choi.matrix)))
         out[key + "_choi_cptp"] = tmg.point_estimate("lifp", cptp=True).choi.matrix
+        out[key + "_states_lin"] = tmg.point_estimate("states", cptp=False).choi.matrix
+        out[key + "_states_lin_cptp"] = tmg.point_estimate("states").choi.matrix
+        if n == 1:
+            out[key + "_states_mle_cptp"] = tmg.point_estimate("states", states_est_method="mle").choi.matrix
         out[key + "_tp_only"] = tmg.tp_projection(ch).choi.matrix
         out[key + "_cp_only"] = tmg.cp_projection(ch).choi.matrix
         print(f"   {key}: n={n} dykstra iters={int(out[key + '_dykstra_iters'])}")
     save("process", **out)
+
+
+# --------------------------------------------------------------------------------------
+# (f) MomentInterval: closed-form CI of the CLI scripts  (interval.py:59-110, stats.py)
+# --------------------------------------------------------------------------------------
+def gen_moment():
+    out = {}
+    cls = np.array([0.5, 0.75, 0.9, 0.99])
+    k = 0
+    for n, povm, shots, seed in ((1, "proj-set", 1000, 1), (2, "proj-set", 10000, 2), (3, "proj-set", 100000, 3),
+                                 (2, "sic", 5000, 4)):
+        rho = ginibre_state(np.random.default_rng(300 + k), 2**n)
+        np.random.seed(seed)
+        t = qp.StateTomograph(qp.Qobj(rho))
+        t.experiment(shots, povm)
+        key = f"S{k}"
+        out[key + "_n"] = np.array(n)
+        out[key + "_povm"] = np.array(povm)
+        out[key + "_counts"] = t.results
+        for distr in ("gamma", "norm", "exp"):
+            iv = qp.MomentInterval(t, distr_type=distr)
+            out[key + "_" + distr] = iv(cls)[0]
+        k += 1
+    out["n_state_cases"] = np.array(k)
+    out["conf_levels"] = cls
+    # process: the notebook case (Moments.ipynb cell 4 prints [0.01529795, 0.01764183, 0.01983802])
+    s_ = 0.2886751345948129
+    s4 = 0.28867513459481287
+    sic_states = [[0.5, s_, s_, s4], [0.5, s_, -s_, -s4], [0.5, -s_, s_, -s4], [0.5, -s_, -s_, s4]]
+    target = [0.5, 0, 0, 0, 0, 0, 0, 0.5, 0, 0, 0.5, 0, 0, 0.5, 0, 0]
+    counts = np.array(json.load(open(os.path.join(REF, "input.json")))["outcomes"])
+    tmg = qp.ProcessTomograph(qp.Channel(qp.Qobj(target)), input_states=[qp.Qobj(b) for b in sic_states])
+    np.random.seed(0)
+    tmg.experiment(10000, "proj-set")
+    tmg.results = counts
+    out["NB_process_radii"] = qp.MomentInterval(tmg)([0.5, 0.75, 0.9])[0]
+    out["NB_process_printed"] = np.array([0.01529795, 0.01764183, 0.01983802])
+    np.random.seed(11)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 2))
+    tmg.experiment(10000, "proj-set")
+    out["C3_counts"] = tmg.results
+    out["C3_process_radii"] = qp.MomentInterval(tmg)(cls)[0]
+    save("moment", **out)
 
 
 # --------------------------------------------------------------------------------------
@@ -490,7 +537,7 @@ def gen_large():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "bootstrap", "large"]
+    which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large"]
     table = {
         "operators": gen_operators,
         "states": gen_states_and_born,
@@ -498,6 +545,7 @@ if __name__ == "__main__":
         "chol": gen_chol_nll,
         "mle": gen_mle,
         "process": gen_process,
+        "moment": gen_moment,
         "bootstrap": gen_bootstrap,
         "large": gen_large,
     }

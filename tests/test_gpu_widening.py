@@ -1,0 +1,98 @@
+"""GPU: the rows SURVEY 8f ranks "next" -- MomentInterval (closed-form CI), the 'states' process
+estimator, and the JSON command-line front ends -- against golden vectors from the reference and the
+reference-held known answers (notebooks/Moments.ipynb cell 4 radii, cell 6 Bloch vector)."""
+import json
+import os
+
+import numpy as np
+import pytest
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qp():
+    import quantpy_amd
+
+    return quantpy_amd
+
+
+def test_moment_interval_state(qp):
+    g = load_golden("moment")
+    cls = g["conf_levels"]
+    for k in range(int(g["n_state_cases"])):
+        key = f"S{k}"
+        n = int(g[key + "_n"])
+        t = qp.StateTomograph(qp.qobj.fully_mixed(n))
+        t.povm_matrix = qp.generate_measurement_matrix(str(g[key + "_povm"]), n)
+        t.results = g[key + "_counts"]
+        for distr in ("gamma", "norm", "exp"):
+            got, _ = qp.MomentInterval(t, distr_type=distr)(cls)
+            assert np.allclose(got, g[key + "_" + distr], rtol=1e-9, atol=0), (key, distr)
+    with pytest.raises(NotImplementedError):
+        qp.MomentInterval(t, distr_type="cauchy")()
+
+
+def test_moment_interval_process_known_answer(qp):
+    g = load_golden("moment")
+    gp = load_golden("process")
+    ins = [qp.Qobj(b) for b in gp["NB_input_blochs"]]
+    tmg = qp.ProcessTomograph(qp.Channel(qp.Qobj([0.5, 0, 0, 0, 0, 0, 0, 0.5, 0, 0, 0.5, 0, 0, 0.5, 0, 0])),
+                              input_states=ins)
+    np.random.seed(0)
+    tmg.experiment(10000, "proj-set")
+    tmg.results = gp["NB_counts"]
+    radii, _ = qp.MomentInterval(tmg)([0.5, 0.75, 0.9])
+    assert np.abs(radii - g["NB_process_printed"]).max() < 5e-9  # the notebook's printed 8 digits
+    assert np.allclose(radii, g["NB_process_radii"], rtol=1e-9)
+    np.random.seed(11)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 2))
+    tmg.experiment(10000, "proj-set")
+    assert np.array_equal(tmg.results, g["C3_counts"])
+    assert np.allclose(qp.MomentInterval(tmg)(g["conf_levels"])[0], g["C3_process_radii"], rtol=1e-8)
+
+
+def test_process_states_method(qp, oracle):
+    g = load_golden("process")
+    makers = {"P0": lambda: qp.channel.depolarizing(0.1, 1), "P1": lambda: qp.operator.H.as_channel(),
+              "C3": lambda: qp.channel.depolarizing(0.1, 2)}
+    for key, mk in makers.items():
+        np.random.seed(int(g[key + "_seed"]))
+        tmg = qp.ProcessTomograph(mk())
+        tmg.experiment(int(g[key + "_shots"]), str(g[key + "_povm"]))
+        assert np.array_equal(tmg.results, g[key + "_counts"])
+        assert np.abs(tmg.point_estimate("states", cptp=False).choi.matrix - g[key + "_states_lin"]).max() < 1e-10
+        assert np.abs(tmg.point_estimate("states").choi.matrix - g[key + "_states_lin_cptp"]).max() < 1e-9
+        if int(g[key + "_n"]) == 1:
+            got = tmg.point_estimate("states", states_est_method="mle").choi.matrix
+            assert np.abs(got - g[key + "_states_mle_cptp"]).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        tmg.point_estimate("pgdb")
+    with pytest.raises(ValueError):
+        tmg.point_estimate("nope")
+
+
+def test_cli_wire_format(qp, tmp_path):
+    """the reference's own input.json (tests/golden/reference_input.json) through both front ends."""
+    from quantpy_amd import cli
+
+    src = os.path.join(GOLDEN, "reference_input.json")
+    out = tmp_path / "out.json"
+    cli.process_interval(["-i", src, "-o", str(out)])
+    res = json.load(open(out))
+    gp, gm = load_golden("process"), load_golden("moment")
+    # input.json truncates the SIC input states to 4 digits: 1.3e-4 from the notebook's full-precision run
+    assert np.abs(np.array(res["process"]) - gp["NB_printed_bloch_nocptp"]).max() < 3e-4
+    assert np.abs(np.array(res["hs_radius"]) - gm["NB_process_printed"]).max() < 1e-4
+    assert len(res["hs_radius"]) == 3
+    # a state file in the same format
+    data = {"povm_matrix": qp.generate_measurement_matrix("proj-set", 1).tolist(),
+            "outcomes": [[5002, 4998], [5028, 4972], [10000, 0]], "conf_levels": [0.5, 0.9]}
+    sfile = tmp_path / "state.json"
+    sfile.write_text(json.dumps(data))
+    res = cli.state_interval(["-i", str(sfile), "--no-ci"])
+    assert "hs_radius" not in res
+    assert np.abs(np.array(res["state"]) - load_golden("counts_lin")["C1_lin_bloch_unphys"]).max() < 1e-13
+    res = cli.state_interval(["-i", str(sfile)])
+    assert len(res["hs_radius"]) == 2 and res["hs_radius"][0] < res["hs_radius"][1]

@@ -207,3 +207,25 @@ def test_sharded_bootstrap_gather_gloo_world2(tmp_path, n_items):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "rank 0/2 ok" in res.stdout and "rank 1/2 ok" in res.stdout
+
+
+def test_moment_sums_host_math_against_reference_radii(oracle):
+    """l2_moments (the reference's twelve stats.py einsums collected into matrix form) with the
+    oracle's CPU left inverse must reproduce the reference's MomentInterval radii."""
+    import scipy.stats as sts
+
+    from quantpy_amd.tomography.interval import l2_moments
+
+    g = load_golden("moment")
+    for k in range(int(g["n_state_cases"])):
+        key = f"S{k}"
+        n = int(g[key + "_n"])
+        dim = 2**n
+        a = oracle.measurement_matrix(str(g[key + "_povm"]), n)
+        counts = g[key + "_counts"]
+        n_meas = counts.sum(-1)
+        inv = oracle.left_inv(a.reshape(-1, a.shape[-1])) / dim
+        mean, var = l2_moments(counts / n_meas[:, None], n_meas[0], inv)
+        scale = var / mean
+        radii = np.sqrt(sts.gamma(a=mean / scale, scale=scale).ppf(g["conf_levels"])) * np.sqrt(dim / 2)
+        assert np.allclose(radii, g[key + "_gamma"], rtol=1e-9), key

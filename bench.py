@@ -62,8 +62,12 @@ def main():
 
     dev_index = 0 if args.share_gpu0 else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("QT_BENCH_FORCE_DIST") == "1"  # (1-rank group: rehearsal of the RCCL path)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -99,7 +103,7 @@ def main():
         eng.mle_dev(counts_d, rho_d, init="lin", max_iter=100, tol=1e-3, nit=nit_d, nfev=nfev_d, status=st_d)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -118,7 +122,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -204,7 +208,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         boot_ms = (time.perf_counter() - tb) * 1e3
-        if world > 1:
+        if use_dist:
             t = torch.tensor([boot_ms], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             boot_ms = float(t.item())
@@ -258,7 +262,7 @@ def main():
             "bootstrap_ci": boot,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

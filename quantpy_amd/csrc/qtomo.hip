@@ -731,16 +731,23 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
                        dst ? dst + b0 : nullptr, h->hess.as<double>()));
     }
   } else {
-    HIPCHK(h->ws_x.ensure(nel * sizeof(double)));
-    HIPCHK(h->ws_g.ensure(nel * sizeof(double)));
-    HIPCHK(h->ws_f.ensure((size_t)B * sizeof(double)));
-    HIPCHK(h->ws_act.ensure((size_t)B * sizeof(int32_t)));
-    double *wx = h->ws_x.as<double>(), *wg = h->ws_g.as<double>(), *wf = h->ws_f.as<double>();
-    int32_t* wact = h->ws_act.as<int32_t>();
-    QT_LAUNCH_SMALL(qt::k_mle_start, h->M, B,
-                    (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
-    QT_LAUNCH_SMALL(qt::k_mle_bfgs, h->M, B,
-                    (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+    // up to one resident wave per SIMD (1024 trial-waves) the single fused launch wins; beyond that the
+    // 256-VGPR BFGS loop would cap occupancy for every trial, so the split pair is used
+    const int waves = (B + (64 / h->D > 0 ? 64 / h->D : 1) - 1) / (64 / h->D > 0 ? 64 / h->D : 1);
+    if (waves <= 1024) {
+      QT_LAUNCH_SMALL(qt::k_mle_fused, h->M, B, (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst));
+    } else {
+      HIPCHK(h->ws_x.ensure(nel * sizeof(double)));
+      HIPCHK(h->ws_g.ensure(nel * sizeof(double)));
+      HIPCHK(h->ws_f.ensure((size_t)B * sizeof(double)));
+      HIPCHK(h->ws_act.ensure((size_t)B * sizeof(int32_t)));
+      double *wx = h->ws_x.as<double>(), *wg = h->ws_g.as<double>(), *wf = h->ws_f.as<double>();
+      int32_t* wact = h->ws_act.as<int32_t>();
+      QT_LAUNCH_SMALL(qt::k_mle_start, h->M, B,
+                      (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+      QT_LAUNCH_SMALL(qt::k_mle_bfgs, h->M, B,
+                      (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+    }
   }
   if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;
   if (int r = fetch_out(h, dnit, nit, (size_t)B, flags)) return r;

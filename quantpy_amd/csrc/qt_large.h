@@ -9,10 +9,14 @@
 //     Jacobi images A / V and the gradient matrix.  At n = 5 with 'proj-set' (M = 6^5 = 7776):
 //     X = 7776, Y = 5184 doubles -> 127 KB.  Frequencies are not stored: they are re-read from the
 //     counts (int64, gathered through the R-order row map) when needed.
-//   * HBM: the BFGS inverse Hessian, D x D f64 per trial (0.5 MB at n = 4, 8 MB at n = 5) in a
-//     caller-provided workspace.  It is exactly symmetric by construction, so thread t reads column t
-//     (coalesced) for H g and for the rank-2 update; H0 = I is never materialised.  This is the one
-//     place on the path that is genuinely HBM-bound: 3 sweeps of H per BFGS iteration.
+//   * The BFGS inverse Hessian is never formed.  A dense D x D f64 H (8 MB per trial at n = 5) had to be
+//     swept three times per iteration and made the loop HBM-bound (measured: 1.3 ms per iteration at
+//     256 concurrent trials = 4.6 TB/s).  Instead the (s_i, y_i) pairs of all iterations so far are kept
+//     (2 D doubles per iteration, in a caller-provided workspace; thread t only ever touches element t
+//     of each pair, so they are private, coalesced streams) and H_k g is evaluated by the two-loop
+//     recursion with H_0 = I -- algebraically the same matrix as scipy's update
+//     H <- (I - rho s y^T) H (I - rho y s^T) + rho s s^T applied k times, at 4 k D flops and 2 k
+//     workgroup reductions instead of 24 MB of traffic.
 // Estimators for n >= 4 require a product POVM (every built-in one is); a dense 7776 x 1024 operand
 // per evaluation per trial would be 64 MB of traffic and is refused rather than run slowly.
 //
@@ -45,8 +49,8 @@ struct Large {
     if (y < 2 * D) y = 2 * D;
     return y + (y & 1);
   }
-  __host__ __device__ static size_t lds_bytes(int M, int R1) {
-    return (size_t)(oTab + 8 * R1 + x_doubles(M) + y_doubles(M, R1)) * sizeof(double);
+  __host__ __device__ static size_t lds_bytes(int M, int R1, int max_iter = 0) {
+    return (size_t)(oTab + 8 * R1 + x_doubles(M) + y_doubles(M, R1) + 2 * max_iter) * sizeof(double);
   }
 
   struct Ctx {
@@ -66,6 +70,7 @@ struct Large {
     __device__ __forceinline__ double* tabP() const { return sm + oTab + 4 * pr.R1; }
     __device__ __forceinline__ double* X() const { return sm + oTab + 8 * pr.R1; }
     __device__ __forceinline__ double* Y() const { return X() + x_doubles(M); }
+    __device__ __forceinline__ double* pair_rho() const { return Y() + y_doubles(M, pr.R1 > 0 ? pr.R1 : 1); }  // [max_iter]
     __device__ __forceinline__ cd* Aimg() const { return reinterpret_cast<cd*>(Y()); }  // overlays Y
     __device__ __forceinline__ cd* Vimg() const { return reinterpret_cast<cd*>(X()); }  // overlays X
   };
@@ -476,13 +481,14 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_nll_large(PovmView pv, const 
   if (grad) grad[(size_t)b * S::D + c.t] = gt;
 }
 
-// a10 for n = 4, 5: the whole MLE of one trial.  `hess` = B x D x D doubles of workspace.
+// a10 for n = 4, 5: the whole MLE of one trial.  `pairs` = B x max_iter x 2 x D doubles of workspace
+// ((s_i, y_i) of every accepted step); LDS carries rho_i and the two-loop alphas (2 x max_iter doubles).
 template <int NQ>
 __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const int64_t* __restrict__ counts, int B,
                                                              int init, int max_iter, double gtol, double* __restrict__ rho,
                                                              int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
                                                              double* __restrict__ fun_out, int32_t* __restrict__ status_out,
-                                                             double* __restrict__ hess) {
+                                                             double* __restrict__ pairs) {
   using S = Large<NQ>;
   constexpr int D = S::D, d = S::d;
   extern __shared__ double smem[];
@@ -508,14 +514,14 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
     const double gnorm = S::bmax(c, fabs(gk));
     if (!(gnorm > gtol) || !(0 < max_iter)) active = false;
   }
-  double* H = hess + (size_t)b * D * D;  // symmetric: thread t works on column t (H[k*D + t])
-  bool h_identity = true;
+  double* my = pairs + (size_t)b * max_iter * 2 * D + c.t;  // s_i[t] at my[2 i D], y_i[t] at my[(2 i + 1) D]
+  double* prho = c.pair_rho();
+  double* palpha = prho + max_iter;
   double old_old = 0.0, pk = 0.0, stp = 0.0;
   LineSearch ls;
-  double* vec = c.vec();
   if (active) {
     old_old = fk + sqrt(S::bsum(c, gk * gk)) / 2.0;
-    pk = -gk;
+    pk = -gk;  // H_0 = I
     ls.start(fk, old_old, S::bsum(c, gk * pk), &stp);
   }
   const int eval_cap = (max_iter + 2) * 130;
@@ -552,35 +558,31 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
       status = 2;
       break;
     }
+    if (!(kiter < max_iter)) break;
     const double ys = S::bsum(c, yk * sk);
     const double rhok = (ys == 0.0) ? 1000.0 : 1.0 / ys;
-    // u = H y ; H += -rho (u s^T + s u^T) + (rho^2 y.u + rho) s s^T   (column t per thread)
-    vec[c.t] = yk;
+    const int np = kiter - 1;  // index of the new pair
+    my[(size_t)(2 * np) * D] = sk;
+    my[(size_t)(2 * np + 1) * D] = yk;
+    if (c.t == 0) prho[np] = rhok;
     __syncthreads();
-    double u = 0.0;
-    if (h_identity) u = yk;
-    else
-      for (int k = 0; k < D; ++k) u = fma(H[(size_t)k * D + c.t], vec[k], u);
-    const double yhy = S::bsum(c, yk * u);
-    double* ub = c.X();  // u | s
-    ub[c.t] = u;
-    ub[D + c.t] = sk;
-    __syncthreads();
-    const double cc = rhok * rhok * yhy + rhok;
-    if (!(kiter < max_iter)) break;
-    vec[c.t] = gk;
-    __syncthreads();
-    // fused: update column t of H and accumulate (H_new g)_t in the same sweep
-    double hp = 0.0;
-    for (int k = 0; k < D; ++k) {
-      const double hold = h_identity ? (k == c.t ? 1.0 : 0.0) : H[(size_t)k * D + c.t];
-      const double hnew = hold + (-rhok * (ub[k] * sk + ub[D + k] * u) + cc * ub[D + k] * sk);
-      H[(size_t)k * D + c.t] = hnew;
-      hp = fma(hnew, vec[k], hp);
+    // two-loop recursion: p = -H_k g with H_0 = I
+    double q = gk;
+    for (int i = np; i >= 0; --i) {
+      const double si = (i == np) ? sk : my[(size_t)(2 * i) * D];
+      const double yi = (i == np) ? yk : my[(size_t)(2 * i + 1) * D];
+      const double a = prho[i] * S::bsum(c, si * q);
+      if (c.t == 0) palpha[i] = a;
+      q = fma(-a, yi, q);
     }
-    h_identity = false;
     __syncthreads();
-    pk = -hp;
+    for (int i = 0; i <= np; ++i) {
+      const double si = (i == np) ? sk : my[(size_t)(2 * i) * D];
+      const double yi = (i == np) ? yk : my[(size_t)(2 * i + 1) * D];
+      const double bb = prho[i] * S::bsum(c, yi * q);
+      q = fma(si, palpha[i] - bb, q);
+    }
+    pk = -q;
     ls.start(fk, old_old, S::bsum(c, gk * pk), &stp);
   }
   if (status == 0 && ok) {

@@ -77,7 +77,7 @@ struct qt_handle {
   DevBuf in0, in1, out0, out1, out2, out3, out4, proc_aug;
   // MLE hand-off between k_mle_start and k_mle_bfgs
   DevBuf ws_x, ws_g, ws_f, ws_act;
-  // BFGS inverse Hessians of the n >= 4 kernels (D x D doubles per trial of a chunk)
+  // BFGS (s, y) history of the n >= 4 kernels (max_iter x 2 D doubles per trial of a chunk)
   DevBuf hess;
   // process tomography
   qt::ProcessState proc;
@@ -204,15 +204,16 @@ int need_product(qt_handle_t* h, bool need_uniform) {
     return fail(QT_ERR_UNSUPPORTED, "n_qubits = %d linear inversion needs equal shots per setting", h->nq);
   return 0;
 }
-#define QT_LAUNCH_LARGE(KERNEL, B_, M_, R1_, ARGS)                                                          \
+#define QT_LAUNCH_LARGE(KERNEL, B_, M_, R1_, ARGS) QT_LAUNCH_LARGE_X(KERNEL, B_, M_, R1_, 0, ARGS)
+#define QT_LAUNCH_LARGE_X(KERNEL, B_, M_, R1_, XTRA_, ARGS)                                                 \
   do {                                                                                                      \
     if (h->nq == 4) {                                                                                       \
-      const size_t lds_ = qt::Large<4>::lds_bytes(M_, R1_);                                                 \
+      const size_t lds_ = qt::Large<4>::lds_bytes(M_, R1_, XTRA_);                                          \
       if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for LDS (%zu B)", lds_);         \
       if (int r_ = allow_big_lds(KERNEL<4>, lds_)) return r_;                                               \
       hipLaunchKernelGGL((KERNEL<4>), dim3(B_), dim3(qt::Large<4>::NT), lds_, h->stream, QT_UNPACK ARGS);   \
     } else {                                                                                                \
-      const size_t lds_ = qt::Large<5>::lds_bytes(M_, R1_);                                                 \
+      const size_t lds_ = qt::Large<5>::lds_bytes(M_, R1_, XTRA_);                                          \
       if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for LDS (%zu B)", lds_);         \
       if (int r_ = allow_big_lds(KERNEL<5>, lds_)) return r_;                                               \
       hipLaunchKernelGGL((KERNEL<5>), dim3(B_), dim3(qt::Large<5>::NT), lds_, h->stream, QT_UNPACK ARGS);   \
@@ -718,17 +719,19 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
   if (int r = stage_out(h, h->out4, status, (size_t)B, flags, &dst)) return r;
   if (h->nq >= 4) {
     if (int r = need_product(h, init == QT_INIT_LIN)) return r;
-    // the inverse Hessians live in HBM: D*D doubles per trial, processed in chunks of <= 4 GiB
-    const size_t per_trial = (size_t)h->D * h->D * sizeof(double);
+    // BFGS history: 2 D doubles per iteration and trial, processed in chunks of <= 4 GiB
+    if (max_iter > 4096) return fail(QT_ERR_UNSUPPORTED, "max_iter > 4096 is not supported for n_qubits >= 4");
+    const size_t per_trial = (size_t)(max_iter > 0 ? max_iter : 1) * 2 * h->D * sizeof(double);
     int chunk = (int)(((size_t)4 << 30) / per_trial);
+    if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     HIPCHK(h->hess.ensure((size_t)chunk * per_trial));
     for (int b0 = 0; b0 < B; b0 += chunk) {
       const int nb = (B - b0 < chunk) ? B - b0 : chunk;
-      QT_LAUNCH_LARGE(qt::k_mle_large, nb, h->M, h->prod.R1,
-                      (h->view(), dc + (size_t)b0 * h->M, nb, init, max_iter, tol, drho + (size_t)b0 * h->D * 2,
-                       dnit ? dnit + b0 : nullptr, dnfev ? dnfev + b0 : nullptr, dfun ? dfun + b0 : nullptr,
-                       dst ? dst + b0 : nullptr, h->hess.as<double>()));
+      QT_LAUNCH_LARGE_X(qt::k_mle_large, nb, h->M, h->prod.R1, max_iter,
+                        (h->view(), dc + (size_t)b0 * h->M, nb, init, max_iter, tol, drho + (size_t)b0 * h->D * 2,
+                         dnit ? dnit + b0 : nullptr, dnfev ? dnfev + b0 : nullptr, dfun ? dfun + b0 : nullptr,
+                         dst ? dst + b0 : nullptr, h->hess.as<double>()));
     }
   } else {
     // up to one resident wave per SIMD (1024 trial-waves) the single fused launch wins; beyond that the

@@ -149,8 +149,11 @@ def main():
         with open(pmc_file) as fh:
             pmc = json.load(fh)
         traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    # qt_mle_batch runs the single-launch kernel while the batch fits one wave per SIMD (<= 1024 waves)
+    dominant_kernel = ("qt::k_mle_fused<3,false>" if B <= 1024 else
+                       "qt::k_mle_start<3,false> (+ qt::k_mle_bfgs<3,false> for the trials that iterate)")
     roofline = {
-        "bound": "hbm", "kernel": "k_mle_start<3,false> (+ k_mle_bfgs<3,false>, which exits at once when no trial iterates)", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": dominant_kernel, "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
         "traffic_source": traffic_src,
         "bytes_per_launch": int(launch_bytes), "kernel_ms": round(kernel_ms, 5),

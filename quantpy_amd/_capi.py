@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqtomo.so")
+LIB_PATH = os.environ.get("QTOMO_LIB") or os.path.join(_HERE, "lib", "libqtomo.so")  # QTOMO_LIB: profile build
 
 QT_HOST_PTR = 0
 QT_DEVICE_PTR = 1

@@ -24,6 +24,19 @@ def _stale():
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def build_profile_library(verbose=False):
+    """Development aid: the same sources with -DQT_PHASE_TIMING -> lib/libqtomo_prof.so (phase stamps
+    inside the kernels; loaded only when QTOMO_LIB points at it, see scripts/phase_timing.py)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    out = os.path.join(LIB_DIR, "libqtomo_prof.so")
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DQT_PHASE_TIMING",
+           "-o", out, os.path.join(CSRC, "qtomo.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -shared -fPIC csrc/qtomo.hip -> lib/libqtomo.so"""
     if not force and not _stale():

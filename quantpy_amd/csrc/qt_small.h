@@ -30,6 +30,26 @@
 
 namespace qt {
 
+// Optional per-wave phase stamps (shader clock) for scripts/phase_timing.py: compiled in only with
+// -DQT_PHASE_TIMING (lib/libqtomo_prof.so); the product library carries none of this.
+#ifdef QT_PHASE_TIMING
+__device__ long long* g_qt_prof = nullptr;  // [waves][32]
+#define QT_STAMP(slot)                                                                                   \
+  do {                                                                                                   \
+    if (g_qt_prof && (threadIdx.x & 63) == 0)                                                            \
+      g_qt_prof[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + (slot)] =           \
+          (long long)__builtin_readcyclecounter();                                                       \
+  } while (0)
+#define QT_STAMP_VAL(slot, val)                                                                          \
+  do {                                                                                                   \
+    if (g_qt_prof && (threadIdx.x & 63) == 0)                                                            \
+      g_qt_prof[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + (slot)] = (val);    \
+  } while (0)
+#else
+#define QT_STAMP(slot) do {} while (0)
+#define QT_STAMP_VAL(slot, val) do {} while (0)
+#endif
+
 struct cd {
   double re, im;
 };
@@ -50,11 +70,14 @@ __device__ __forceinline__ void wave_sync() {
 // ---- group reductions on the DPP network (no LDS round trips) ---------------------------------
 // A butterfly inside rows of 16 lanes (quad_perm, row_half_mirror, row_mirror) and, for G = 64,
 // four v_readlane across the rows.  Every lane of a group ends with the same bits.
-template <int CTRL>
+template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double dpp_f64(double v) {
+  // Full row mask: every lane has a source under the permutations used here, so bound_ctrl lets the
+  // compiler drop the zero-initialisation of the destination.  Partial row mask (row_bcast steps):
+  // the rows left out must read as 0.
   const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -65,25 +88,39 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 __device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }  // NaN wins
 
+// Across the four rows of a wavefront: row_bcast15 adds the total of row 0 / 2 into row 1 / 3,
+// row_bcast31 adds lane 31 (rows 0+1) into rows 2 and 3, lane 63 then holds (r2 + r3) + (r0 + r1) and
+// is handed to every lane through an SGPR pair (6 + 2 instructions instead of 8 readlanes + 7).
 template <int G>
 __device__ __forceinline__ double gsum(double v) {
   v += dpp_f64<0xB1>(v);                 // quad_perm [1,0,3,2]
   v += dpp_f64<0x4E>(v);                 // quad_perm [2,3,0,1]
   if (G >= 8) v += dpp_f64<0x141>(v);    // row_half_mirror
   if (G >= 16) v += dpp_f64<0x140>(v);   // row_mirror
-  if (G == 64) v = (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+  if (G == 64) {
+    v += dpp_f64<0x142, 0xA>(v);         // row_bcast15 -> rows 1, 3
+    v += dpp_f64<0x143, 0xC>(v);         // row_bcast31 -> rows 2, 3
+    v = readlane_f64(v, 63);
+  }
   return v;
 }
+// Maximum of non-negative values (every caller passes fabs(.)); a NaN anywhere wins.  The rows a
+// row_bcast step leaves out read 0, which is neutral for such inputs.
 template <int G>
 __device__ __forceinline__ double gmax(double v) {
   v = nanmax(v, dpp_f64<0xB1>(v));
   v = nanmax(v, dpp_f64<0x4E>(v));
   if (G >= 8) v = nanmax(v, dpp_f64<0x141>(v));
   if (G >= 16) v = nanmax(v, dpp_f64<0x140>(v));
-  if (G == 64)
-    v = nanmax(nanmax(readlane_f64(v, 0), readlane_f64(v, 16)), nanmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+  if (G == 64) {
+    v = nanmax(v, dpp_f64<0x142, 0xA>(v));
+    v = nanmax(v, dpp_f64<0x143, 0xC>(v));
+    v = readlane_f64(v, 63);
+  }
   return v;
 }
+
+constexpr bool kLiftSingleNegative = true;  // a7 short cut of Small::lift_single_negative (n = 3)
 
 // 1/sqrt(x) for normal-range positive x: hardware seed (v_rsq_f64) plus two Newton steps -- ~8
 // dependent FP64 instructions instead of the ~25 of a correctly rounded sqrt-then-divide,
@@ -200,6 +237,7 @@ struct PovmView {
   const double* PinvT; // [M][D]  transpose of the left inverse of A'
   int M;
   ProductView pr;
+  double jtol2 = 1e-28;  // Jacobi stops when off-diagonal norm^2 <= jtol2 * Frobenius norm^2
 };
 
 template <int NQ, bool ALDS>
@@ -213,11 +251,16 @@ struct Small {
   static constexpr int TPB = TPW * WPB;    // trials per workgroup
   static constexpr int T = d * (d - 1) / 2;
   static constexpr int LDA = D + 1;        // row pitch of the LDS operand image
+  // Row pitch of the d x d complex matrix images: 9 at d = 8, so that the rows one column is read
+  // from (pitch 144 B = 36 banks) fall on distinct LDS banks; a pitch of 8 (128 B) makes every such
+  // ds_read_b128 a 4-way bank conflict.  d = 2, 4 have no conflict to begin with.
+  static constexpr int LD = d == 8 ? 9 : d;
+  static constexpr int MAT = 2 * LD * d;   // doubles per matrix image
   // per-trial LDS scratch, in doubles
-  static constexpr int oA = 0;             // complex [d][d]
-  static constexpr int oB = oA + 2 * D;    // complex [d][d]
-  static constexpr int oV = oB + 2 * D;    // complex [d][d]
-  static constexpr int oVec = oV + 2 * D;  // [D]
+  static constexpr int oA = 0;             // complex [d][LD]
+  static constexpr int oB = oA + MAT;      // complex [d][LD]
+  static constexpr int oV = oB + MAT;      // complex [d][LD]
+  static constexpr int oVec = oV + MAT;    // [D]
   static constexpr int oLam = oVec + D;    // [d] (+ pad to even)
   static constexpr int oM = oLam + 2 * ((d + 1) / 2);  // rbuf[Mp], freq[Mp], bufB[Mp], tables[8 R1]
   __host__ __device__ static int trial_doubles(int M, int R1 = 0) {
@@ -231,7 +274,7 @@ struct Small {
 
   // ---- per-lane context ---------------------------------------------------------------
   struct Ctx {
-    int l, i, j;     // lane in group, matrix element
+    int l, i, j, e;  // lane in group, matrix element, its slot i * LD + j in a matrix image
     double* sm;      // this trial's LDS scratch
     double* img;     // the workgroup's operand image (ALDS)
     int M, Mp;
@@ -267,6 +310,7 @@ struct Small {
     const int slot = wave * TPW + lane / G;
     c.i = c.l / d;
     c.j = c.l % d;
+    c.e = c.i * LD + c.j;
     c.M = pv.M;
     c.Mp = (pv.M + 1) & ~1;
     c.pv = pv;
@@ -334,7 +378,7 @@ struct Small {
     cd s{0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < d; ++r) {
-      const cd e = m[r * d + (r ^ c.xm)];  // conj(M[r][r^x]) summed with the sign of P_k[r][r^x]
+      const cd e = m[r * LD + (r ^ c.xm)];  // conj(M[r][r^x]) summed with the sign of P_k[r][r^x]
       const double sg = (__popc(r & c.zm) & 1) ? -1.0 : 1.0;
       s.re += sg * e.re;
       s.im -= sg * e.im;
@@ -468,21 +512,21 @@ struct Small {
     const double nrm = gsum<G>(a.re * a.re + a.im * a.im);  // Frobenius norm: invariant
     for (int sweep = 0; sweep < 20; ++sweep) {
       const double off = gsum<G>(i != j ? a.re * a.re + a.im * a.im : 0.0);
-      if (__all(!(off > 1e-28 * nrm))) break;
+      if (__all(!(off > c.pv.jtol2 * nrm))) break;
 #pragma unroll 1
       for (int r = 1; r < d; ++r) {
-        Ai[c.l] = a;
-        Vi[c.l] = v;
+        Ai[c.e] = a;
+        Vi[c.e] = v;
         wave_sync();
         const int pj = j ^ r, pi = i ^ r;
         const int cp = j < pj ? j : pj, cq = j < pj ? pj : j;  // column pair, ordered
         const int rp = i < pi ? i : pi, rq = i < pi ? pi : i;  // row pair, ordered
-        const double c_pp = Ai[cp * d + cp].re, c_qq = Ai[cq * d + cq].re;
-        const cd c_pq = Ai[cp * d + cq];
-        const double r_pp = Ai[rp * d + rp].re, r_qq = Ai[rq * d + rq].re;
-        const cd r_pq = Ai[rp * d + rq];
-        const cd a_c = Ai[i * d + pj], a_r = Ai[pi * d + j], a_x = Ai[pi * d + pj];
-        const cd v_c = Vi[i * d + pj];
+        const double c_pp = Ai[cp * LD + cp].re, c_qq = Ai[cq * LD + cq].re;
+        const cd c_pq = Ai[cp * LD + cq];
+        const double r_pp = Ai[rp * LD + rp].re, r_qq = Ai[rq * LD + rq].re;
+        const cd r_pq = Ai[rp * LD + rq];
+        const cd a_c = Ai[i * LD + pj], a_r = Ai[pi * LD + j], a_x = Ai[pi * LD + pj];
+        const cd v_c = Vi[i * LD + pj];
         wave_sync();  // all reads of this image are issued before the next round overwrites it
         double cj, ci;
         cd wj, wi;
@@ -500,14 +544,14 @@ struct Small {
     }
     // rebuild with clipped eigenvalues: R_ij = sum_k V_ik max(lam_k, eps) conj(V_jk)
     double* lam = c.lam();
-    Vi[c.l] = v;
+    Vi[c.e] = v;
     if (i == j) lam[i] = a.re;
     wave_sync();
     cd rr{0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < d; ++k) {
       const double lc = lam[k] > eps ? lam[k] : eps;  // np.maximum(eps, v)
-      const cd p = cmulc(Vi[i * d + k], Vi[j * d + k]);
+      const cd p = cmulc(Vi[i * LD + k], Vi[j * LD + k]);
       rr.re += lc * p.re;
       rr.im += lc * p.im;
     }
@@ -518,34 +562,132 @@ struct Small {
 
   // ---- a8: lower Cholesky factor of the matrix whose element this lane holds.
   // Leaves L in Bm() (upper part zero) and returns the lane's parameter x_l; ok = 0 if not PD.
-  __device__ static double cholesky_param(const Ctx& c, cd a, int& ok) {
+  // The elimination is carried on past a non-positive pivot as L S L^dagger (S = signs), so that by
+  // Sylvester's law `neg` is the number of negative eigenvalues (99 when a pivot is too small for
+  // the count to mean anything) and `kneg` the first index where the leading block stops being PD.
+  __device__ static double cholesky_param(const Ctx& c, cd a, int& ok, int* neg_out = nullptr, int* kneg_out = nullptr) {
     cd* A = c.A();
     cd* L = c.Bm();
     const int i = c.i, j = c.j;
-    A[c.l] = a;
-    L[c.l] = cd{0.0, 0.0};
-    ok = 1;
+    A[c.e] = a;
+    L[c.e] = cd{0.0, 0.0};
+    int neg = 0, kneg = d - 1;
     wave_sync();
 #pragma unroll 1
     for (int k = 0; k < d; ++k) {
-      const double akk = A[k * d + k].re;
-      if (!(akk > 0.0)) ok = 0;
-      const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);  // 1 / l_kk
-      const cd aik = A[i * d + k], ajk = A[j * d + k];
+      const double akk = A[k * LD + k].re;
+      const double mag = fabs(akk);
+      const bool pos = akk > 0.0;
+      if (!pos) {
+        if (neg == 0) kneg = k;
+        ++neg;
+      }
+      if (!(mag > 1e-13)) neg = neg > 0 ? 99 : neg;  // NaN lands here too
+      const double rs = fast_rsqrt(mag > 1e-300 ? mag : 1e-300);  // 1 / |l_kk|
+      const cd aik = A[i * LD + k], ajk = A[j * LD + k];
       const cd lik{aik.re * rs, aik.im * rs}, ljk{ajk.re * rs, ajk.im * rs};
-      if (j == k && i >= k) L[c.l] = (i == k) ? cd{akk * rs, 0.0} : lik;
+      if (j == k && i >= k) L[c.e] = (i == k) ? cd{akk * rs, 0.0} : lik;
       if (i > k && j > k) {
         const cd p = cmulc(lik, ljk);
-        a.re -= p.re;
-        a.im -= p.im;
-        A[c.l] = a;
+        a.re = pos ? a.re - p.re : a.re + p.re;
+        a.im = pos ? a.im - p.im : a.im + p.im;
+        A[c.e] = a;
       }
       wave_sync();
     }
-    const cd e = L[c.pi * d + c.pj];
+    ok = neg == 0;
+    if (neg_out) *neg_out = neg;
+    if (kneg_out) *kneg_out = kneg;
+    const cd e = L[c.pi * LD + c.pj];
     const double x = c.pkind == 2 ? e.im : e.re;
     wave_sync();
     return x;
+  }
+
+  // ---- a7, short cut for exactly ONE negative eigenvalue (lam_1 < 0 < lam_2 <= ...):
+  //   U max(v, eps) U^dagger = A + (eps - lam_1) v_1 v_1^dagger,
+  // so only the projector N = v_1 v_1^dagger is needed.  M = A^{-1} (Gauss-Jordan, pivot order with
+  // `kneg` last: the leading block is positive definite, so no pivoting is needed) has v_1 as its
+  // dominant direction whenever |lam_1| < lam_2; N <- N N^dagger / Tr squares the separation
+  // ratio each time (k squarings = 2^k inverse-iteration steps at the cost of k 8x8 products).
+  // Certified, not assumed: purity Tr N^2 -> 1 (then one more squaring: contamination < 1e-14),
+  // lam_1 = Tr(A N) < eps, and ||A N - lam_1 N||_F <= 1e-13 ||A||_F.  Returns false (caller runs the
+  // Jacobi eigensolver on the untouched input) on a slow ratio, a positive lam, or a failed check.
+  __device__ static bool lift_single_negative(const Ctx& c, cd r, int kneg, double eps, cd& out) {
+    static_assert(G == 64, "one trial per wavefront: the flags below are wave-uniform");
+    cd* Ai = c.A();
+    cd* Vi = c.V();
+    const int i = c.i, j = c.j;
+    if (i == j) r.im = 0.0;
+    cd b = r;
+#pragma unroll 1
+    for (int s = 0; s < d; ++s) {
+      const int p = s < kneg ? s : (s < d - 1 ? s + 1 : kneg);
+      Ai[c.e] = b;
+      wave_sync();
+      const double piv = Ai[p * LD + p].re;
+      const cd bip = Ai[i * LD + p], bpj = Ai[p * LD + j];
+      wave_sync();
+      double inv = __builtin_amdgcn_rcp(piv);
+      inv = fma(inv, fma(-piv, inv, 1.0), inv);
+      inv = fma(inv, fma(-piv, inv, 1.0), inv);
+      const cd t{bpj.re * inv, bpj.im * inv};
+      const cd e = cmul(bip, t);
+      cd nb{b.re - e.re, b.im - e.im};
+      if (j == p) nb = cd{-bip.re * inv, -bip.im * inv};
+      if (i == p) nb = (j == p) ? cd{inv, 0.0} : t;
+      b = nb;
+    }
+    QT_STAMP(4);
+    // X_k is kept at Frobenius norm 1, i.e. sum sigma_i^2 = 1; then ||X_k X_k^dagger||_F^2 = sum sigma_i^4
+    // is the purity of that spectrum: one reduction per squaring gives both the scale and the test.
+    b = cscale(b, fast_rsqrt(gsum<G>(b.re * b.re + b.im * b.im)));
+    bool certified = false, done = false;
+#pragma unroll 1
+    for (int k = 1; k <= 7 && !done; ++k) {
+      Ai[c.e] = b;
+      wave_sync();
+      cd n{0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < d; ++q) {
+        const cd u = Ai[i * LD + q], v = Ai[j * LD + q];
+        n.re = fma(u.re, v.re, fma(u.im, v.im, n.re));
+        n.im = fma(u.im, v.re, fma(-u.re, v.im, n.im));
+      }
+      wave_sync();
+      const double pur = gsum<G>(n.re * n.re + n.im * n.im);
+      b = cscale(n, fast_rsqrt(pur));
+      const double defect = 1.0 - pur;  // ~ 2 (sigma_2 / sigma_1)^(2^(k+1))
+      QT_STAMP_VAL(20, k);
+      if (certified) done = true;
+      else if (defect < 1e-7) certified = true;
+      else if (k == 3 && !(defect < 0.05)) return false;  // ratio > ~0.8: the eigensolver is cheaper
+    }
+    QT_STAMP(5);
+    if (!done) return false;
+    if (i == j) b.im = 0.0;
+    b = cscale(b, 1.0 / gsum<G>(i == j ? b.re : 0.0));      // N = X / Tr X
+    const double lam = gsum<G>(r.re * b.re + r.im * b.im);  // Tr(A N) = sum_ij A_ij conj(N_ij)
+    if (!(lam < eps)) return false;
+    Ai[c.e] = r;
+    Vi[c.e] = b;
+    wave_sync();
+    cd q{-lam * b.re, -lam * b.im};
+#pragma unroll
+    for (int k = 0; k < d; ++k) {  // (A N)_ij, N Hermitian
+      const cd u = Ai[i * LD + k], v = Vi[j * LD + k];
+      q.re = fma(u.re, v.re, fma(u.im, v.im, q.re));
+      q.im = fma(u.im, v.re, fma(-u.re, v.im, q.im));
+    }
+    wave_sync();
+    const double res2 = gsum<G>(q.re * q.re + q.im * q.im);
+    const double nrm2 = gsum<G>(r.re * r.re + r.im * r.im);
+    if (!(res2 <= 1e-26 * nrm2)) return false;
+    const double w = eps - lam;
+    cd o{fma(w, b.re, r.re), fma(w, b.im, r.im)};
+    const double tr = gsum<G>(i == j ? o.re : 0.0);
+    out = cd{o.re / tr, o.im / tr};
+    return true;
   }
 
   // a7 with the positive-definite shortcut: when the Hermitian input is numerically positive
@@ -553,15 +695,25 @@ struct Small {
   // U max(v, 1e-15) U^dagger is the input itself (to rounding) and only the trace division is left.
   // Returns the projected element; if `xl` is non-null also the Cholesky parameter of the result.
   __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out) {
-    int ok;
-    double x = cholesky_param(c, r, ok);
+    int ok, neg, kneg;
+    double x = cholesky_param(c, r, ok, &neg, &kneg);
+    QT_STAMP(3);
     const double tr = gsum<G>(c.i == c.j ? r.re : 0.0);
     cd out{r.re / tr, r.im / tr};
     x = x / sqrt(tr);  // L of r/tr
     if (!__all(ok)) {
-      const cd proj = psd_project(c, r, 1e-15);  // whole wave runs it; PD trials keep their shortcut
+      cd proj;
+      bool lifted = false;
+      if constexpr (G == 64) {  // one trial per wave: neg / kneg are the same in every lane
+        if (kLiftSingleNegative && __builtin_amdgcn_readfirstlane(neg) == 1)
+          lifted = __builtin_amdgcn_readfirstlane(
+                       (int)lift_single_negative(c, r, __builtin_amdgcn_readfirstlane(kneg), 1e-15, proj)) != 0;
+      }
+      if (!lifted) proj = psd_project(c, r, 1e-15);  // whole wave runs it; PD trials keep their shortcut
+      QT_STAMP(6);
       int ok2 = 1;
       const double x2 = xl ? cholesky_param(c, proj, ok2) : 0.0;
+      QT_STAMP(7);
       if (!ok) {
         out = proj;
         x = x2;
@@ -587,24 +739,27 @@ struct Small {
       const int t = (i * (i - 1)) / 2 + j;
       lij = cd{vx[d + t], vx[d + T + t]};
     }
-    L[c.l] = lij;
+    L[c.e] = lij;
     wave_sync();
     cd m{0.0, 0.0};
     const int kmax = i < j ? i : j;
 #pragma unroll
     for (int k = 0; k < d; ++k)
-      if (k <= kmax) m = cadd(m, cmulc(L[i * d + k], L[j * d + k]));
+      if (k <= kmax) m = cadd(m, cmulc(L[i * LD + k], L[j * LD + k]));
     return m;
   }
 
   // ---- a9: NLL value and exact gradient at x (image = Aw).  Needs freq[] loaded.  Leaves L in Bm().
   __device__ static void nll_grad(const Ctx& c, double xl, double& f, double& gl) {
     double tr;
+    QT_STAMP(11);
     const cd m = build_llh(c, xl, tr);
+    QT_STAMP(12);
     cd* A = c.A();
-    A[c.l] = cd{m.re / tr, m.im / tr};  // rho
+    A[c.e] = cd{m.re / tr, m.im / tr};  // rho
     wave_sync();
     const double bl = bloch_of(c, A);
+    QT_STAMP(13);
     double* vec = c.vec();
     vec[c.l] = bl;
     wave_sync();
@@ -626,6 +781,7 @@ struct Small {
         tab += n_out;
         in = out;
       }
+      QT_STAMP(14);
       for (int o = c.l; o < c.M; o += G) {  // stage n fused with the log-likelihood terms
         const double xn = stage_value<true>(c.tabT(), R1, tab[o], 1, in);
         const double wrow = c.pv.pr.wrowR[o];
@@ -635,7 +791,9 @@ struct Small {
       }
       f = -gsum<G>(fpart);
       wave_sync();
+      QT_STAMP(15);
       wl = prod_backward(c, c.tabT(), rb);
+      QT_STAMP(16);
     } else {
       for (int m0 = 0; m0 < c.M; m0 += G) {
         const int mm = m0 + c.l;
@@ -654,21 +812,23 @@ struct Small {
     vec[c.l] = wl;
     wave_sync();
     cd g = matrix_of(c, vec);
+    QT_STAMP(17);
     g.re = -g.re;
     g.im = -g.im;
     if (c.i == c.j) g.re -= tr_g_rho;
     g.re /= tr;
     g.im /= tr;
-    A[c.l] = g;
+    A[c.e] = g;
     wave_sync();
     // Q = Gt L ; gradient entries 2 Re Q_ii, 2 Re Q_ij, 2 Im Q_ij (i > j)
     const cd* L = c.Bm();
     cd q{0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < d; ++k)
-      if (k >= c.pj) q = cadd(q, cmul(A[c.pi * d + k], L[k * d + c.pj]));
+      if (k >= c.pj) q = cadd(q, cmul(A[c.pi * LD + k], L[k * LD + c.pj]));
     gl = 2.0 * (c.pkind == 2 ? q.im : q.re);
     wave_sync();
+    QT_STAMP(18);
   }
 };
 
@@ -688,11 +848,15 @@ __global__ void __launch_bounds__(256) k_lin_batch(PovmView pv, const int64_t* _
   bool live;
   const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;  // padding groups recompute the last trial; nothing is stored
+  QT_STAMP(0);
   S::load_image(c, pv.PinvT);
   S::load_freq(c, counts + (size_t)bb * pv.M);
+  QT_STAMP(1);
   double bl;
   cd r = S::lin_invert(c, bl);
+  QT_STAMP(2);
   if (physical) r = S::make_feasible(c, r, nullptr, nullptr);
+  QT_STAMP(9);
   if (live) {
     double* out = rho + ((size_t)b * S::D + c.l) * 2;
     out[0] = r.re;
@@ -986,22 +1150,27 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
   bool live;
   const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;
+  QT_STAMP(0);
   S::load_freq(c, counts + (size_t)bb * pv.M);
+  QT_STAMP(1);
   int ok;
   double xk;
   if (init == 0) {
     S::load_image(c, pv.PinvT);
     double bl;
     const cd lin = S::lin_invert(c, bl);
+    QT_STAMP(2);
     S::load_image(c, pv.Aw);
     S::make_feasible(c, lin, &xk, &ok);
   } else {
     S::load_image(c, pv.Aw);
     xk = S::cholesky_param(c, cd{c.i == c.j ? 1.0 / d : 0.0, 0.0}, ok);
   }
+  QT_STAMP(8);
   double fk, gk;
   S::nll_grad(c, xk, fk, gk);
   const double gnorm = gmax<G>(fabs(gk));
+  QT_STAMP(9);
   const bool iterate = live && ok && (gnorm > gtol) && (0 < max_iter);
   if (!iterate) {
     int status = 0;
@@ -1025,6 +1194,7 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
       }
     }
   }
+  QT_STAMP(10);
   if (!__any(iterate)) return;  // per wave
   if (!iterate) {                // finite dummies for the groups of this wave that are already done
     xk = (c.l < d) ? 1.0 : 0.0;

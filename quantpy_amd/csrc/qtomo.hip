@@ -83,7 +83,8 @@ struct qt_handle {
   qt::ProcessState proc;
   bool proc_set = false;
 
-  qt::PovmView view() const { return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod}; }
+  qt::PovmView view() const { return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod, jtol2}; }
+  double jtol2 = getenv("QT_JACOBI_TOL2") ? atof(getenv("QT_JACOBI_TOL2")) : 1e-28;
 };
 
 namespace {
@@ -918,3 +919,11 @@ int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode
 }
 
 }  // extern "C"
+
+#ifdef QT_PHASE_TIMING
+// profile build only (scripts/phase_timing.py): where the kernels drop their phase stamps
+extern "C" int qt_debug_set_prof(void* device_ptr) {
+  long long* p = static_cast<long long*>(device_ptr);
+  return hipMemcpyToSymbol(HIP_SYMBOL(qt::g_qt_prof), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif

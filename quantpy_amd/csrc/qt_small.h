@@ -268,8 +268,28 @@ struct Small {
     return oM + (R1 > 0 ? 3 : 2) * Mp + 8 * R1;
   }
   __host__ __device__ static int image_doubles(int M) { return ALDS ? ((M * LDA + 1) & ~1) : 0; }
+  // Index tables of a product POVM, staged once per workgroup (shared by its waves): forward stage
+  // tables, backward stage tables, R-order row map.
+  __host__ __device__ static int ipow_h(int b, int e) {
+    int r = 1;
+    for (int t = 0; t < e; ++t) r *= b;
+    return r;
+  }
+  __host__ __device__ static int fwd_ints(int R1) {
+    int t = 0;
+    for (int q = 1; q <= NQ; ++q) t += ipow_h(R1, q) << (2 * (NQ - q));
+    return t;
+  }
+  __host__ __device__ static int bwd_ints(int R1) {
+    int t = 0;
+    for (int q = 1; q <= NQ; ++q) t += ipow_h(R1, q - 1) << (2 * (NQ - q + 1));
+    return t;
+  }
+  __host__ __device__ static int table_doubles(int M, int R1) {
+    return R1 > 0 ? (fwd_ints(R1) + bwd_ints(R1) + M + 1) / 2 : 0;
+  }
   __host__ __device__ static size_t lds_bytes(int M, int R1 = 0) {
-    return ((size_t)image_doubles(M) + (size_t)TPB * trial_doubles(M, R1)) * sizeof(double);
+    return ((size_t)image_doubles(M) + table_doubles(M, R1) + (size_t)TPB * trial_doubles(M, R1)) * sizeof(double);
   }
 
   // ---- per-lane context ---------------------------------------------------------------
@@ -277,6 +297,7 @@ struct Small {
     int l, i, j, e;  // lane in group, matrix element, its slot i * LD + j in a matrix image
     double* sm;      // this trial's LDS scratch
     double* img;     // the workgroup's operand image (ALDS)
+    const int *tfwd, *tbwd, *trmap;  // the workgroup's copy of the product-POVM index tables (LDS)
     int M, Mp;
     PovmView pv;
     // Pauli string k = l:  P_k[r][r ^ xm] = (-i)^ny (-1)^popc(r & zm)
@@ -315,7 +336,19 @@ struct Small {
     c.Mp = (pv.M + 1) & ~1;
     c.pv = pv;
     c.img = smem_block;
-    c.sm = smem_block + image_doubles(pv.M) + slot * trial_doubles(pv.M, pv.pr.enabled ? pv.pr.R1 : 0);
+    const int r1 = pv.pr.enabled ? pv.pr.R1 : 0;
+    int* tabs = reinterpret_cast<int*>(smem_block + image_doubles(pv.M));
+    c.tfwd = tabs;
+    c.tbwd = tabs + fwd_ints(r1);
+    c.trmap = c.tbwd + bwd_ints(r1);
+    if (r1 > 0) {  // every thread of the workgroup comes through here once, before anything else
+      const int nf = fwd_ints(r1), nb = bwd_ints(r1);
+      for (int e = threadIdx.x; e < nf; e += NT) tabs[e] = pv.pr.fwd[e];
+      for (int e = threadIdx.x; e < nb; e += NT) tabs[nf + e] = pv.pr.bwd[e];
+      for (int e = threadIdx.x; e < pv.M; e += NT) tabs[nf + nb + e] = pv.pr.rmap[e];
+      __syncthreads();
+    }
+    c.sm = smem_block + image_doubles(pv.M) + table_doubles(pv.M, r1) + slot * trial_doubles(pv.M, r1);
     int xm = 0, zm = 0, ny = 0;
 #pragma unroll
     for (int b = 0; b < NQ; ++b) {
@@ -403,17 +436,26 @@ struct Small {
   // counts of this trial -> freq[] in LDS (counts / sum(counts): state.py:193, :227).  For a product
   // POVM the frequencies are stored in R-order and the one-qubit tables are staged next to them.
   __device__ static void load_freq(const Ctx& c, const int64_t* counts) {
+    // one coalesced pass over the counts (the only HBM latency of the trial): values parked in rbuf
     double part = 0.0;
-    for (int m = c.l; m < c.M; m += G) part += (double)counts[m];
-    const double tot = gsum<G>(part);
+    double* raw = c.rbuf();
+    for (int m = c.l; m < c.M; m += G) {
+      const double v = (double)counts[m];
+      raw[m] = v;
+      part += v;
+    }
     if (c.prod()) {
-      for (int m = c.l; m < c.M; m += G) c.freq()[m] = (double)counts[c.pv.pr.rmap[m]] / tot;
       for (int e = c.l; e < 4 * c.pv.pr.R1; e += G) {
         c.tabT()[e] = c.pv.pr.T[e];
         c.tabP()[e] = c.pv.pr.P1T[e];
       }
+    }
+    const double inv = 1.0 / gsum<G>(part);
+    wave_sync();
+    if (c.prod()) {
+      for (int m = c.l; m < c.M; m += G) c.freq()[m] = raw[c.trmap[m]] * inv;
     } else {
-      for (int m = c.l; m < c.M; m += G) c.freq()[m] = (double)counts[m] / tot;
+      for (int m = c.l; m < c.M; m += G) c.freq()[m] = raw[m] * inv;
     }
     wave_sync();
   }
@@ -427,7 +469,10 @@ struct Small {
   // One stage: out[o] = sum_t tbl(sel, t) * in[base + t * stride], (base, sel) = tab[o].
   // FWD: 4 terms, tbl(sel, t) = tb[sel*4 + t] (row `sel` of the table);  backward: R1 terms,
   // tbl(sel, t) = tb[t*4 + sel] (column `sel`).
-  template <bool FWD>
+  // One output of a contraction stage.  R1C > 0 fixes the table height at compile time (backward
+  // stages sum R1 terms): the R1 pairs of LDS reads are then issued together instead of one
+  // read-wait-FMA round trip per term, which is what a run-time trip count compiles to.
+  template <bool FWD, int R1C = 0>
   __device__ __forceinline__ static double stage_value(const double* tb, int R1, int ent, int stride, const double* in) {
     const int base = ent & 0xffff, sel = ent >> 16;
     if (FWD) {
@@ -436,21 +481,53 @@ struct Small {
                  fma(row[2], in[base + 2 * stride], fma(row[1], in[base + stride], row[0] * in[base])));
     }
     double acc = 0.0;
+    if (R1C > 0) {
+      double tv[R1C > 0 ? R1C : 1], iv[R1C > 0 ? R1C : 1];
+#pragma unroll
+      for (int t = 0; t < R1C; ++t) {
+        tv[t] = tb[t * 4 + sel];
+        iv[t] = in[base + t * stride];
+      }
+#pragma unroll
+      for (int t = 0; t < R1C; ++t) acc = fma(tv[t], iv[t], acc);
+      return acc;
+    }
     for (int t = 0; t < R1; ++t) acc = fma(tb[t * 4 + sel], in[base + t * stride], acc);
     return acc;
+  }
+  // All outputs of a stage, two per lane and pass so that their reads overlap.
+  template <bool FWD, int R1C>
+  __device__ __forceinline__ static void stage_run(const Ctx& c, const double* tb, const int* tab, int n_out, int stride,
+                                                   const double* in, double* out) {
+    const int R1 = c.pv.pr.R1;
+    for (int o = c.l; o < n_out; o += 2 * G) {
+      const int o2 = o + G;
+      const bool two = o2 < n_out;
+      const int e0 = tab[o], e1 = tab[two ? o2 : o];
+      const double v0 = stage_value<FWD, R1C>(tb, R1, e0, stride, in);
+      const double v1 = stage_value<FWD, R1C>(tb, R1, e1, stride, in);
+      out[o] = v0;
+      if (two) out[o2] = v1;
+    }
   }
   template <bool FWD>
   __device__ static void stage(const Ctx& c, const double* tb, const int* tab, int n_out, int stride, const double* in,
                                double* out) {
-    const int R1 = c.pv.pr.R1;
-    for (int o = c.l; o < n_out; o += G) out[o] = stage_value<FWD>(tb, R1, tab[o], stride, in);
+    if (FWD) stage_run<true, 0>(c, tb, tab, n_out, stride, in, out);
+    else if (c.pv.pr.R1 == 6) stage_run<false, 6>(c, tb, tab, n_out, stride, in, out);
+    else if (c.pv.pr.R1 == 4) stage_run<false, 4>(c, tb, tab, n_out, stride, in, out);
+    else stage_run<false, 0>(c, tb, tab, n_out, stride, in, out);
     wave_sync();
+  }
+  template <int R1C>
+  __device__ __forceinline__ static double stage_last(const Ctx& c, const double* tb, const int* tab, const double* in) {
+    return stage_value<false, R1C>(tb, c.pv.pr.R1, tab[c.l], 1 << (2 * (NQ - 1)), in);
   }
   // Backward pass from Y_n (R-order, in `yn`) to the lane's Y_0[k = l]; tb = tabT (A^T y) or tabP (A^+ f).
   // Intermediates ping-pong between bufB and rbuf; `yn` itself is only read.
   __device__ static double prod_backward(const Ctx& c, const double* tb, const double* yn) {
     const int R1 = c.pv.pr.R1;
-    const int* tab = c.pv.pr.bwd;
+    const int* tab = c.tbwd;
     const double* in = yn;
     double* bufs[2] = {c.bufB(), c.rbuf()};
     int which = 0;
@@ -463,7 +540,10 @@ struct Small {
       in = bufs[which];
       which ^= 1;
     }
-    return stage_value<false>(tb, R1, tab[c.l], 1 << (2 * (NQ - 1)), in);  // stage 1: D outputs, one per lane
+    // stage 1: D outputs, one per lane
+    if (R1 == 6) return stage_last<6>(c, tb, tab, in);
+    if (R1 == 4) return stage_last<4>(c, tb, tab, in);
+    return stage_last<0>(c, tb, tab, in);
   }
   // sum_m Op[m][lane] * vec[m]   (lane = column)
   __device__ __forceinline__ static double col_dot(const Ctx& c, const double* g_rowmajor, const double* vec) {
@@ -484,7 +564,7 @@ struct Small {
         bloch_l = prod_backward(c, c.tabP(), c.freq()) / (c.pv.pr.wuni * d);
       } else {  // unequal shots per setting: dense left inverse, rows visited in R-order
         double acc = 0.0;
-        for (int m = 0; m < c.M; ++m) acc = fma(c.pv.PinvT[(size_t)c.pv.pr.rmap[m] * D + c.l], c.freq()[m], acc);
+        for (int m = 0; m < c.M; ++m) acc = fma(c.pv.PinvT[(size_t)c.trmap[m] * D + c.l], c.freq()[m], acc);
         bloch_l = acc / d;
       }
     } else {
@@ -750,13 +830,15 @@ struct Small {
   }
 
   // ---- a9: NLL value and exact gradient at x (image = Aw).  Needs freq[] loaded.  Leaves L in Bm().
-  __device__ static void nll_grad(const Ctx& c, double xl, double& f, double& gl) {
+  __device__ static void nll_grad(const Ctx& c, double xl, double& f, double& gl, cd* rho_l = nullptr) {
     double tr;
     QT_STAMP(11);
     const cd m = build_llh(c, xl, tr);
     QT_STAMP(12);
     cd* A = c.A();
-    A[c.e] = cd{m.re / tr, m.im / tr};  // rho
+    const cd rho_e{m.re / tr, m.im / tr};
+    if (rho_l) *rho_l = rho_e;
+    A[c.e] = rho_e;
     wave_sync();
     const double bl = bloch_of(c, A);
     QT_STAMP(13);
@@ -770,7 +852,7 @@ struct Small {
     double wl;
     if (c.prod()) {
       const int R1 = c.pv.pr.R1;
-      const int* tab = c.pv.pr.fwd;
+      const int* tab = c.tfwd;
       const double* in = vec;
 #pragma unroll
       for (int q = 1; q < NQ; ++q) {  // stages 1 .. n-1; the last of them lands in bufB
@@ -962,7 +1044,8 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
     xk = S::cholesky_param(c, cd{c.i == c.j ? 1.0 / d : 0.0, 0.0}, ok);
   }
   double fk, gk;
-  S::nll_grad(c, xk, fk, gk);
+  cd rho_l;  // L L^dagger / Tr at x_k: what the trial returns if BFGS does not move
+  S::nll_grad(c, xk, fk, gk, &rho_l);
   const double gnorm = gmax<G>(fabs(gk));
   const bool iterate = ok && (gnorm > gtol) && (0 < max_iter);
   int status = 0;
@@ -972,12 +1055,10 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
     if (0 >= max_iter) status = 3;
     else if (gnorm != gnorm || fk != fk || xn != xn) status = 4;
   }
-  double tr;
-  const cd m = S::build_llh(c, xk, tr);
   if (live) {
     double* out = rho + ((size_t)b * D + c.l) * 2;
-    out[0] = m.re / tr;
-    out[1] = m.im / tr;
+    out[0] = rho_l.re;
+    out[1] = rho_l.im;
     if (iterate) {  // the hand-off is written only for trials that go on to k_mle_bfgs
       ws_x[(size_t)b * D + c.l] = xk;
       ws_g[(size_t)b * D + c.l] = gk;
@@ -1168,7 +1249,8 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
   }
   QT_STAMP(8);
   double fk, gk;
-  S::nll_grad(c, xk, fk, gk);
+  cd rho_l;
+  S::nll_grad(c, xk, fk, gk, &rho_l);
   const double gnorm = gmax<G>(fabs(gk));
   QT_STAMP(9);
   const bool iterate = live && ok && (gnorm > gtol) && (0 < max_iter);
@@ -1180,12 +1262,10 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
       if (0 >= max_iter) status = 3;
       else if (gnorm != gnorm || fk != fk || xn != xn) status = 4;
     }
-    double tr;
-    const cd m = S::build_llh(c, xk, tr);
     if (live) {
       double* out = rho + ((size_t)b * D + c.l) * 2;
-      out[0] = m.re / tr;
-      out[1] = m.im / tr;
+      out[0] = rho_l.re;
+      out[1] = rho_l.im;
       if (c.l == 0) {
         if (nit_out) nit_out[b] = 0;
         if (nfev_out) nfev_out[b] = ok ? 1 : 0;

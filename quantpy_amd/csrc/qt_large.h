@@ -385,8 +385,8 @@ struct Large {
       const double wrow = c.pr.wrowR[o];
       const double pe = xn * wrow * d + 1e-10;
       const double fr = freq(c, o);
-      fpart += fr * log(pe);
-      c.X()[o] = wrow * fr / pe;
+      fpart += fr * fast_log(pe);
+      c.X()[o] = wrow * fr * recip_nr(pe);
     }
     f = -bsum(c, fpart);  // barriers inside publish X
     const double wl = prod_backward(c, c.tabT());

@@ -120,6 +120,43 @@ __device__ __forceinline__ double gmax(double v) {
   return v;
 }
 
+// log(x) and 1/x for the likelihood terms.  The OCML log is correctly rounded through ~85 FP64
+// instructions of double-double arithmetic; the NLL needs neither that nor the special cases beyond
+// "x <= 0 or NaN gives NaN / -inf", and a lone wave pays for every instruction.  x = m 2^e with
+// m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), log m = 2 s (1 + s^2/3 + s^4/5 + ...): with
+// s^2 <= 0.0295 ten terms reach 2^-55; error ~1.5 ulp.  About 30 instructions.
+__device__ __forceinline__ double recip_nr(double x) {  // 1/x to ~1 ulp: hardware seed + two Newton steps
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+__device__ __forceinline__ double fast_log(double x) {
+  if (!(x > 0.0) || !(x < 1.7e308)) return x == 0.0 ? -__builtin_huge_val() : (x > 0.0 ? x : __builtin_nan(""));
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool low = m < 0.70710678118654752440;
+  m = low ? m + m : m;
+  e = low ? e - 1 : e;
+  const double num = m - 1.0, den = m + 1.0;
+  const double r = recip_nr(den);
+  double sq = num * r;
+  sq = fma(r, fma(-sq, den, num), sq);  // s = num / den, correctly rounded up to the last bit
+  const double z = sq * sq;
+  double pl = 1.0 / 21.0;
+  pl = fma(pl, z, 1.0 / 19.0);
+  pl = fma(pl, z, 1.0 / 17.0);
+  pl = fma(pl, z, 1.0 / 15.0);
+  pl = fma(pl, z, 1.0 / 13.0);
+  pl = fma(pl, z, 1.0 / 11.0);
+  pl = fma(pl, z, 1.0 / 9.0);
+  pl = fma(pl, z, 1.0 / 7.0);
+  pl = fma(pl, z, 1.0 / 5.0);
+  pl = fma(pl, z, 1.0 / 3.0);
+  const double lm = fma(sq + sq, pl * z, sq + sq);  // 2 s (1 + z P(z))
+  const double ed = (double)e;
+  return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));  // e ln2 (hi + lo) + log m
+}
+
 constexpr bool kLiftSingleNegative = true;  // a7 short cut of Small::lift_single_negative (n = 3)
 
 // 1/sqrt(x) for normal-range positive x: hardware seed (v_rsq_f64) plus two Newton steps -- ~8
@@ -285,8 +322,9 @@ struct Small {
     for (int q = 1; q <= NQ; ++q) t += ipow_h(R1, q - 1) << (2 * (NQ - q + 1));
     return t;
   }
+  __host__ __device__ static int table_ints(int M, int R1) { return (fwd_ints(R1) + bwd_ints(R1) + M + 1) & ~1; }
   __host__ __device__ static int table_doubles(int M, int R1) {
-    return R1 > 0 ? (fwd_ints(R1) + bwd_ints(R1) + M + 1) / 2 : 0;
+    return R1 > 0 ? table_ints(M, R1) / 2 + M : 0;  // index tables, then the row weights wrowR[M]
   }
   __host__ __device__ static size_t lds_bytes(int M, int R1 = 0) {
     return ((size_t)image_doubles(M) + table_doubles(M, R1) + (size_t)TPB * trial_doubles(M, R1)) * sizeof(double);
@@ -298,6 +336,7 @@ struct Small {
     double* sm;      // this trial's LDS scratch
     double* img;     // the workgroup's operand image (ALDS)
     const int *tfwd, *tbwd, *trmap;  // the workgroup's copy of the product-POVM index tables (LDS)
+    const double* twrow;             // ... and of the row weights N_s / sum(N), R-order
     int M, Mp;
     PovmView pv;
     // Pauli string k = l:  P_k[r][r ^ xm] = (-i)^ny (-1)^popc(r & zm)
@@ -341,11 +380,16 @@ struct Small {
     c.tfwd = tabs;
     c.tbwd = tabs + fwd_ints(r1);
     c.trmap = c.tbwd + bwd_ints(r1);
+    double* wrow = smem_block + image_doubles(pv.M) + table_ints(pv.M, r1) / 2;
+    c.twrow = wrow;
     if (r1 > 0) {  // every thread of the workgroup comes through here once, before anything else
       const int nf = fwd_ints(r1), nb = bwd_ints(r1);
       for (int e = threadIdx.x; e < nf; e += NT) tabs[e] = pv.pr.fwd[e];
       for (int e = threadIdx.x; e < nb; e += NT) tabs[nf + e] = pv.pr.bwd[e];
-      for (int e = threadIdx.x; e < pv.M; e += NT) tabs[nf + nb + e] = pv.pr.rmap[e];
+      for (int e = threadIdx.x; e < pv.M; e += NT) {
+        tabs[nf + nb + e] = pv.pr.rmap[e];
+        wrow[e] = pv.pr.wrowR[e];
+      }
       __syncthreads();
     }
     c.sm = smem_block + image_doubles(pv.M) + table_doubles(pv.M, r1) + slot * trial_doubles(pv.M, r1);
@@ -650,12 +694,15 @@ struct Small {
     cd* L = c.Bm();
     const int i = c.i, j = c.j;
     A[c.e] = a;
-    L[c.e] = cd{0.0, 0.0};
     int neg = 0, kneg = d - 1;
+    cd lmine{0.0, 0.0};  // this lane's element of L (its column j is final after step k = j)
     wave_sync();
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < d; ++k) {
-      const double akk = A[k * LD + k].re;
+      // The pivot sits in the register of lane (k, k): with one trial per wave it is taken from there
+      // (v_readlane), so that 1/sqrt runs while the column is still on its way through LDS.
+      const double akk = (G == 64) ? readlane_f64(a.re, k * d + k) : A[k * LD + k].re;
+      const cd aik = A[i * LD + k], ajk = A[j * LD + k];
       const double mag = fabs(akk);
       const bool pos = akk > 0.0;
       if (!pos) {
@@ -664,20 +711,27 @@ struct Small {
       }
       if (!(mag > 1e-13)) neg = neg > 0 ? 99 : neg;  // NaN lands here too
       const double rs = fast_rsqrt(mag > 1e-300 ? mag : 1e-300);  // 1 / |l_kk|
-      const cd aik = A[i * LD + k], ajk = A[j * LD + k];
-      const cd lik{aik.re * rs, aik.im * rs}, ljk{ajk.re * rs, ajk.im * rs};
-      if (j == k && i >= k) L[c.e] = (i == k) ? cd{akk * rs, 0.0} : lik;
-      if (i > k && j > k) {
-        const cd p = cmulc(lik, ljk);
-        a.re = pos ? a.re - p.re : a.re + p.re;
-        a.im = pos ? a.im - p.im : a.im + p.im;
+      const cd lik{aik.re * rs, aik.im * rs};
+      if (j == k && i >= k) lmine = (i == k) ? cd{akk * rs, 0.0} : lik;
+      if (k + 1 < d) {
+        // a_ij -= s l_ik conj(l_jk), branch-free (both column reads are issued together; lanes outside
+        // the trailing block recompute their old value and store it again)
+        const double srs = pos ? -rs : rs;
+        const cd ljs{ajk.re * srs, ajk.im * srs};  // -s l_jk
+        const bool upd = i > k && j > k;
+        const double nre = fma(lik.re, ljs.re, fma(lik.im, ljs.im, a.re));
+        const double nim = fma(lik.im, ljs.re, fma(-lik.re, ljs.im, a.im));
+        a.re = upd ? nre : a.re;
+        a.im = upd ? nim : a.im;
         A[c.e] = a;
+        wave_sync();
       }
-      wave_sync();
     }
     ok = neg == 0;
     if (neg_out) *neg_out = neg;
     if (kneg_out) *kneg_out = kneg;
+    L[c.e] = lmine;
+    wave_sync();
     const cd e = L[c.pi * LD + c.pj];
     const double x = c.pkind == 2 ? e.im : e.re;
     wave_sync();
@@ -704,8 +758,8 @@ struct Small {
     for (int s = 0; s < d; ++s) {
       const int p = s < kneg ? s : (s < d - 1 ? s + 1 : kneg);
       Ai[c.e] = b;
+      const double piv = readlane_f64(b.re, p * d + p);  // from lane (p, p): no LDS wait before 1 / pivot
       wave_sync();
-      const double piv = Ai[p * LD + p].re;
       const cd bip = Ai[i * LD + p], bpj = Ai[p * LD + j];
       wave_sync();
       double inv = __builtin_amdgcn_rcp(piv);
@@ -866,10 +920,10 @@ struct Small {
       QT_STAMP(14);
       for (int o = c.l; o < c.M; o += G) {  // stage n fused with the log-likelihood terms
         const double xn = stage_value<true>(c.tabT(), R1, tab[o], 1, in);
-        const double wrow = c.pv.pr.wrowR[o];
+        const double wrow = c.twrow[o];
         const double pe = xn * wrow * d + 1e-10;
-        fpart += fr[o] * log(pe);
-        rb[o] = wrow * fr[o] / pe;  // Y_n = w (.) r : A'^T r = K^T (w (.) r)
+        fpart += fr[o] * fast_log(pe);
+        rb[o] = wrow * fr[o] * recip_nr(pe);  // Y_n = w (.) r : A'^T r = K^T (w (.) r)
       }
       f = -gsum<G>(fpart);
       wave_sync();
@@ -881,8 +935,8 @@ struct Small {
         const int mm = m0 + c.l;
         if (mm < c.M) {
           const double pe = row_dot(c, c.pv.AwT, mm, vec) * d + 1e-10;
-          fpart += fr[mm] * log(pe);
-          rb[mm] = fr[mm] / pe;
+          fpart += fr[mm] * fast_log(pe);
+          rb[mm] = fr[mm] * recip_nr(pe);
         }
       }
       f = -gsum<G>(fpart);

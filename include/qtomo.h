@@ -142,6 +142,13 @@ int qt_process_get_operators(qt_handle_t* h, double* lifp_oper, double* lifp_ope
  * projection of process.py:231-257 (n_iter <= 1000, stop 1e-12); iters[B] (nullable) */
 int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double* choi, int32_t* iters,
                   int32_t* status, int flags);
+/* 'pgdb' (process.py:291-308): projected gradient descent with backtracking from the fully mixed Choi
+ * matrix, raw counts as weights, every arithmetic quirk of the reference kept (see qt_process.h).
+ * stop_rule 0 = the reference's loop exit (leaves at the first step that lowers the NLL by more than
+ * tol and returns the point BEFORE it -- in practice the starting point); 1 = accept steps until the
+ * decrease falls below tol.  iters[B], status[B] nullable. */
+int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, double tol, int stop_rule, double* choi,
+                  int32_t* iters, int32_t* status, int flags);
 /* projections alone (process.py:231-278): mode 0 = CPTP (Dykstra), 1 = TP, 2 = CP */
 int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode, int n_iter, double tol,
                           double* choi_out, int32_t* iters, int flags);

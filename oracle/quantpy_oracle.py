@@ -755,3 +755,55 @@ def cptp_projection(choi, n, n_iter=1000, tol=1e-12, return_iters=False):
             break
     out = vec2mat(x)
     return (out, it + 1) if return_iters else out
+
+
+def pgdb_estimate(counts, povm_matrix, in_states, n_iter=1000, tol=1e-10, stop="reference", return_info=False):
+    """'pgdb' (process.py:291-308): projected gradient descent with backtracking on the Choi vector,
+    started at the fully mixed state, raw counts as weights (`_unnorm_results`, process.py:213).
+    The reference's arithmetic is kept: numpy.dot(D, grad) WITHOUT conjugation (:300), log of the complex
+    probabilities (:313), ordering of complex numbers as NumPy orders them (real part first).
+    stop='reference' is the loop of the reference as written -- `if nll(old) - nll(new) > tol: break`
+    (:303-305) leaves at the first step that lowers the NLL by more than tol and the point BEFORE that
+    step is returned; stop='converged' accepts the step and stops when the decrease drops below tol."""
+    counts = np.asarray(counts)
+    n = int(round(math.log2(in_states[0].shape[0])))
+    oper = lifp_operator(in_states, povm_matrix, counts[0].sum(-1))
+    unnorm = np.hstack([c.flatten() for c in counts]).astype(float)
+    dim2 = oper.shape[1]
+
+    def nll(v):
+        return -np.sum(unnorm * np.log(oper @ v + 1e-12))  # complex, as in the reference
+
+    def gt(a, b):  # NumPy's ordering of complex scalars: lexicographic
+        a, b = complex(a), complex(b)
+        return (a.real, a.imag) > (b.real, b.imag)
+
+    dch = int(round(math.sqrt(dim2)))
+    v = mat2vec(np.eye(dch, dtype=np.complex128) / dch)
+    mu, gamma = 1.5 / 4**n, 0.3
+    it, trace = 0, []
+    for it in range(n_iter):
+        probas = oper @ v
+        grad = -oper.T.conj() @ (unnorm / probas)
+        direction = mat2vec(cptp_projection(vec2mat(v - grad / mu), n)) - v
+        alpha = 1.0
+        f0 = nll(v)
+        dot = np.dot(direction, grad)
+        while gt(nll(v + alpha * direction) - f0, gamma * alpha * dot):
+            alpha /= 2
+        new = v + alpha * direction
+        f1 = nll(new)
+        trace.append(dict(alpha=alpha, f0=f0, f1=f1, dot=dot))
+        if stop == "reference":
+            if gt(f0 - f1, tol):
+                break
+            v = new
+        else:
+            v = new
+            if not gt(f0 - f1, tol):
+                it += 1
+                break
+    else:
+        it = n_iter
+    choi = vec2mat(v)
+    return (choi, dict(iters=it, trace=trace)) if return_info else choi

@@ -349,6 +349,130 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT) k_lifp_batch(const int64_t* __
   }
 }
 
+// 'pgdb' (process.py:291-308): projected gradient descent with backtracking on the Choi vector,
+//   c_0 = vec(I / D)                       (fully_mixed(2n), process.py:292)
+//   p = A c,  g = -A^H (n / p)             (n = raw counts; :296-297)
+//   Dir = P_CPTP(c - g / mu) - c,  mu = 1.5 / 4^n                      (:298, :293)
+//   alpha = 1; while nll(c + alpha Dir) - nll(c) > gamma alpha <Dir, g>: alpha /= 2   (gamma = 0.3; :299-301)
+//   nll(c) = -sum n log(A c + 1e-12)                                   (:310-314)
+// kept with the reference's arithmetic: <Dir, g> is numpy.dot -- no conjugation, i.e.
+// sum (Dr Gr - Di Gi) for the Hermitian pair -- and log of a complex number enters through its
+// real part log|z|.  stop_rule 0 is the reference's loop exit (:303-305): it leaves when a step
+// LOWERS the NLL by more than tol and returns the point BEFORE that step; stop_rule 1 is the
+// evident intent (accept the step, stop when the decrease falls below tol).
+// One workgroup per process; thread (i, j) owns Choi element C[i][j]; vectors are column-stacked
+// (v = col * DC + row, routines.py:59-61).  A = lifp [R][NE] complex, R = D * M.
+template <int DC>
+__global__ void __launch_bounds__(ProcWG<DC>::NT) k_pgdb_batch(const int64_t* __restrict__ counts, int B, int M,
+                                                              const double* __restrict__ lifp, int n_iter, double tol,
+                                                              int stop_rule, double* __restrict__ choi,
+                                                              int32_t* __restrict__ iters, int32_t* __restrict__ status) {
+  using W = ProcWG<DC>;
+  constexpr int NE = W::NE, NT = W::NT, NW = NT / 64;
+  __shared__ typename W::Sh sh;
+  __shared__ double cre[NE], cim[NE], dre[NE], dim_[NE];  // current point / direction, index v
+  extern __shared__ double dynsh[];                       // cnt[R] | p[R] | q[R] | w[R]
+  const int R = DC * M;
+  double* cnt = dynsh;
+  double* pr = cnt + R;
+  double* qr = pr + R;
+  double* wr = qr + R;
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool act = tid < NE;
+  const int i = tid / DC, j = tid % DC;
+  const int v_own = j * DC + i;  // where this thread's element sits in the column-stacked vector
+  for (int r = tid; r < R; r += NT) cnt[r] = (double)counts[(size_t)b * R + r];
+  double xr = (act && i == j) ? 1.0 / DC : 0.0, xi = 0.0;
+  const double mu = 1.5 / DC, gamma = 0.3;
+  // Re(A x) for a Hermitian-vector x held in LDS (xre, xim): one wave per row, lanes over columns
+  auto row_products = [&](const double* xre, const double* xim, double* out) {
+    for (int r = wave; r < R; r += NW) {
+      const double* a = lifp + (size_t)r * NE * 2;
+      double acc = 0.0;
+      for (int v = lane; v < NE; v += 64) acc += a[2 * v] * xre[v] - a[2 * v + 1] * xim[v];
+      for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+      if (lane == 0) out[r] = acc;
+    }
+  };
+  auto nll_at = [&](double alpha) {
+    double part = 0.0;
+    for (int r = tid; r < R; r += NT) part += cnt[r] * log(fabs(pr[r] + alpha * qr[r] + 1e-12));
+    return -block_sum<NT>(part, sh.red);
+  };
+  int it = 0;
+  int bad = 0;
+  for (; it < n_iter; ++it) {
+    __syncthreads();
+    if (act) {
+      cre[v_own] = xr;
+      cim[v_own] = xi;
+    }
+    __syncthreads();
+    row_products(cre, cim, pr);
+    __syncthreads();
+    for (int r = tid; r < R; r += NT) wr[r] = cnt[r] / pr[r];
+    __syncthreads();
+    // g_v = -sum_r conj(A[r][v]) w_r   (thread v; consecutive threads read consecutive columns)
+    double gr = 0.0, gi = 0.0;
+    if (act) {
+      for (int r = 0; r < R; ++r) {
+        const double w = wr[r];
+        gr -= lifp[((size_t)r * NE + tid) * 2] * w;
+        gi += lifp[((size_t)r * NE + tid) * 2 + 1] * w;
+      }
+      dre[tid] = gr;  // parked in the direction buffer, index v = tid
+      dim_[tid] = gi;
+    }
+    __syncthreads();
+    double gmr = 0.0, gmi = 0.0;  // gradient element of this thread's (i, j)
+    if (act) {
+      gmr = dre[v_own];
+      gmi = dim_[v_own];
+    }
+    __syncthreads();
+    double tr_ = xr - gmr / mu, ti_ = xi - gmi / mu;
+    W::dykstra(sh, act, i, j, tr_, ti_, 1000, 1e-12);
+    const double ddr = tr_ - xr, ddi = ti_ - xi;
+    if (act) {
+      dre[v_own] = ddr;
+      dim_[v_own] = ddi;
+    }
+    __syncthreads();
+    row_products(dre, dim_, qr);
+    const double dg = block_sum<NT>(act ? ddr * gmr - ddi * gmi : 0.0, sh.red);  // numpy.dot(D, grad)
+    const double f0 = nll_at(0.0);
+    double alpha = 1.0, f1 = nll_at(1.0);
+    for (int h = 0; h < 1100 && (f1 - f0 > gamma * alpha * dg); ++h) {
+      alpha *= 0.5;
+      f1 = nll_at(alpha);
+    }
+    if (!(f0 == f0) || !(f1 == f1)) bad = 1;
+    if (stop_rule == 0) {
+      if (f0 - f1 > tol) break;  // the reference leaves here, WITHOUT taking the step
+      xr += alpha * ddr;
+      xi += alpha * ddi;
+    } else {
+      xr += alpha * ddr;
+      xi += alpha * ddi;
+      if (!(f0 - f1 > tol)) {
+        ++it;
+        break;
+      }
+    }
+  }
+  if (act) {
+    double* out = choi + ((size_t)b * NE + tid) * 2;
+    out[0] = xr;
+    out[1] = xi;
+  }
+  if (tid == 0) {
+    if (iters) iters[b] = it;
+    if (status) status[b] = bad ? 4 : 0;
+  }
+}
+
 // mode 0: Dykstra CPTP, 1: TP only, 2: CP only  (process.py:231-278)
 template <int DC>
 __global__ void __launch_bounds__(ProcWG<DC>::NT) k_cptp_project(const double* __restrict__ in, int B, int mode,

@@ -893,6 +893,37 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
   return count_bad(status, B, flags);
 }
 
+int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, double tol, int stop_rule, double* choi,
+                  int32_t* iters, int32_t* status, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
+  if (B < 0 || (B > 0 && (!counts || !choi))) return fail(QT_ERR_ARG, "bad pgdb_batch arguments");
+  if (stop_rule != 0 && stop_rule != 1) return fail(QT_ERR_ARG, "stop_rule must be 0 (reference) or 1 (converged)");
+  if (n_iter < 0) return fail(QT_ERR_ARG, "n_iter must be >= 0");
+  if (B == 0) return 0;
+  const int D = h->D, M = h->M;
+  const int64_t* dc;
+  double* dchoi;
+  int32_t *dit, *dst;
+  if (int r = stage_in(h, h->in0, counts, (size_t)B * D * M, flags, &dc)) return r;
+  if (int r = stage_out(h, h->out0, choi, (size_t)B * D * D * 2, flags, &dchoi)) return r;
+  if (int r = stage_out(h, h->out1, iters, (size_t)B, flags, &dit)) return r;
+  if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
+  const size_t dyn = (size_t)4 * D * M * sizeof(double);
+  if (dyn > 32 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the process kernel");
+  if (D == 4)
+    hipLaunchKernelGGL(qt::k_pgdb_batch<4>, dim3(B), dim3(qt::ProcWG<4>::NT), dyn, h->stream, dc, B, M,
+                       (const double*)h->proc.lifp, n_iter, tol, stop_rule, dchoi, dit, dst);
+  else
+    hipLaunchKernelGGL(qt::k_pgdb_batch<16>, dim3(B), dim3(qt::ProcWG<16>::NT), dyn, h->stream, dc, B, M,
+                       (const double*)h->proc.lifp, n_iter, tol, stop_rule, dchoi, dit, dst);
+  if (int r = fetch_out(h, dchoi, choi, (size_t)B * D * D * 2, flags)) return r;
+  if (int r = fetch_out(h, dit, iters, (size_t)B, flags)) return r;
+  if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
+  if (int r = finish(h, flags)) return r;
+  return count_bad(status, B, flags);
+}
+
 int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode, int n_iter, double tol, double* choi_out,
                           int32_t* iters, int flags) {
   if (int r = check_handle(h)) return r;

@@ -194,6 +194,25 @@ class Engine:
             choi, iters = choi[0], iters[0]
         return (choi, iters) if return_iters else choi
 
+    def pgdb(self, counts, n_iter=1000, tol=1e-10, stop="reference", return_iters=False):
+        """'pgdb' of process.py:291-308 on counts (B, D, S, K) or (D, S, K) -> Choi.  stop='reference'
+        keeps the reference's loop exit (it returns the point before the first improving step),
+        stop='converged' accepts steps until the NLL decrease falls below `tol`."""
+        if stop not in ("reference", "converged"):
+            raise ValueError("stop must be 'reference' or 'converged'")
+        c = _i64(counts)
+        single = c.ndim == 3
+        c = c.reshape(-1, self.D, self.S, self.K)
+        b = c.shape[0]
+        choi = np.empty((b, self.D, self.D), dtype=np.complex128)
+        iters = np.zeros(b, dtype=np.int32)
+        status = np.zeros(b, dtype=np.int32)
+        self._chk(self.lib.qt_pgdb_batch(self._h, _ptr(c), b, int(n_iter), float(tol), 0 if stop == "reference" else 1,
+                                         _ptr(choi), _ptr(iters), _ptr(status), _capi.QT_HOST_PTR))
+        if single:
+            choi, iters = choi[0], iters[0]
+        return (choi, iters) if return_iters else choi
+
     def lifp_dev(self, counts, choi, cptp=True, iters=None, status=None):
         self._chk(self.lib.qt_lifp_batch(self._h, _ptr(counts), counts.shape[0], int(bool(cptp)), _ptr(choi), _ptr(iters),
                                          _ptr(status), _capi.QT_DEVICE_PTR))

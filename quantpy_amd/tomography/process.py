@@ -80,17 +80,23 @@ class ProcessTomograph:
         return eng
 
     def point_estimate(self, method="lifp", cptp=True, n_iter=1000, tol=1e-10, states_est_method="lin",
-                       states_physical=True, states_init="lin"):
+                       states_physical=True, states_init="lin", *, pgdb_stop="reference"):
         """method 'lifp': Choi matrix by linear inversion of all frequencies at once, then (if
         `cptp`) the alternating projection onto completely positive trace-preserving maps.
-        'pgdb' and 'states' of the reference are not on the GPU hot path."""
+        'states': from the reconstructed output states.  'pgdb': projected gradient descent with
+        backtracking (reference process.py:291-308).  The reference's loop leaves at the first step
+        that lowers the NLL by more than `tol` and returns the point before it -- normally the fully
+        mixed start; that behaviour is the default here (`pgdb_stop='reference'`, a drop-in), and
+        `pgdb_stop='converged'` (keyword-only extension) iterates to convergence instead."""
         if method == "states":
             return self._point_estimate_states(cptp, states_est_method, states_physical, states_init, n_iter, tol)
         if method == "pgdb":
-            # measured: the reference's 'pgdb' (process.py:291-308) leaves its loop at the first step that
-            # lowers the NLL and returns the fully mixed starting point; there is nothing to be in parity with
-            raise NotImplementedError("method='pgdb' is not provided (the reference implementation returns its "
-                                      "fully mixed starting point)")
+            eng = self._engine()
+            self._unnorm_results = np.hstack([tmg.flat_results for tmg in self.tomographs])
+            choi, iters = eng.pgdb(self.results, n_iter=n_iter, tol=tol, stop=pgdb_stop, return_iters=True)
+            self.pgdb_iterations = int(iters)
+            self.reconstructed_channel = Channel(choi)
+            return self.reconstructed_channel
         if method != "lifp":
             raise ValueError("Incorrect value for argument `method`")
         eng = self._engine()

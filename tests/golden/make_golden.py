@@ -536,8 +536,72 @@ def gen_large():
     save("large", **out)
 
 
+# --------------------------------------------------------------------------------------
+# (f) 'pgdb' process estimator (process.py:291-308): what the reference returns, the pieces of its
+# first iteration, and the same loop driven to convergence through the reference's own methods
+# --------------------------------------------------------------------------------------
+def gen_pgdb():
+    from quantpy.routines import _mat2vec, _vec2mat
+    from quantpy.qobj import fully_mixed
+
+    out = {}
+    cases = [
+        ("P0", 1, lambda: qp.channel.depolarizing(0.1, 1), 10000, "proj-set", 11),
+        ("P2", 1, lambda: qp.channel.amplitude_damping(0.3), 5000, "sic", 13),
+        ("C3", 2, lambda: qp.channel.depolarizing(0.1, 2), 10000, "proj-set", 11),
+    ]
+    for key, n, mk, shots, povm, seed in cases:
+        np.random.seed(seed)
+        tmg = qp.ProcessTomograph(mk())
+        tmg.experiment(shots, povm)
+        out[key + "_n"] = np.array(n)
+        out[key + "_povm"] = np.array(povm)
+        out[key + "_counts"] = tmg.results
+        out[key + "_input_states"] = np.stack([s_.matrix for s_ in tmg.input_basis.elements])
+        ch = tmg.point_estimate("pgdb")  # the reference as it is
+        out[key + "_returned"] = ch.choi.matrix
+        # first iteration, piece by piece, with the reference's own operators and methods
+        v = _mat2vec(fully_mixed(n * 2).matrix)
+        mu, gamma = 1.5 / 4**n, 0.3
+        probas = tmg._lifp_oper @ v
+        grad = -tmg._lifp_oper.T.conj() @ (tmg._unnorm_results / probas)
+        direction = tmg._cptp_projection_vec(v - grad / mu) - v
+        alpha = 1
+        while tmg._nll(v + alpha * direction) - tmg._nll(v) > gamma * alpha * np.dot(direction, grad):
+            alpha /= 2
+        out[key + "_it0_probas"] = probas
+        out[key + "_it0_grad"] = grad
+        out[key + "_it0_direction"] = direction
+        out[key + "_it0_alpha"] = np.array(alpha)
+        out[key + "_it0_dot"] = np.array(np.dot(direction, grad))
+        out[key + "_it0_nll"] = np.array([tmg._nll(v), tmg._nll(v + alpha * direction)])
+        # the loop with the step accepted and the exit on a small decrease, capped at 20 iterations
+        cap, tol = 20, 1e-10
+        nlls = []
+        for it in range(cap):
+            probas = tmg._lifp_oper @ v
+            grad = -tmg._lifp_oper.T.conj() @ (tmg._unnorm_results / probas)
+            direction = tmg._cptp_projection_vec(v - grad / mu) - v
+            alpha = 1
+            while tmg._nll(v + alpha * direction) - tmg._nll(v) > gamma * alpha * np.dot(direction, grad):
+                alpha /= 2
+            new = v + alpha * direction
+            f0, f1 = tmg._nll(v), tmg._nll(new)
+            nlls.append([f0, f1, alpha])
+            v = new
+            if not (f0 - f1 > tol):
+                break
+        out[key + "_conv_cap"] = np.array(cap)
+        out[key + "_conv_choi"] = _vec2mat(v)
+        out[key + "_conv_trace"] = np.array(nlls)
+        print(f"   {key}: returned == start: {np.allclose(ch.choi.matrix, fully_mixed(n * 2).matrix)}; "
+              f"converged variant: {len(nlls)} steps, nll {nlls[0][0].real:.6f} -> {nlls[-1][1].real:.6f}")
+    save("pgdb", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large"]
+    which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large",
+                             "pgdb"]
     table = {
         "operators": gen_operators,
         "states": gen_states_and_born,
@@ -548,6 +612,7 @@ if __name__ == "__main__":
         "moment": gen_moment,
         "bootstrap": gen_bootstrap,
         "large": gen_large,
+        "pgdb": gen_pgdb,
     }
     for w in which:
         print(f"[{w}]")

@@ -67,8 +67,6 @@ def test_process_states_method(qp, oracle):
         if int(g[key + "_n"]) == 1:
             got = tmg.point_estimate("states", states_est_method="mle").choi.matrix
             assert np.abs(got - g[key + "_states_mle_cptp"]).max() < 1e-6
-    with pytest.raises(NotImplementedError):
-        tmg.point_estimate("pgdb")
     with pytest.raises(ValueError):
         tmg.point_estimate("nope")
 
@@ -96,3 +94,35 @@ def test_cli_wire_format(qp, tmp_path):
     assert np.abs(np.array(res["state"]) - load_golden("counts_lin")["C1_lin_bloch_unphys"]).max() < 1e-13
     res = cli.state_interval(["-i", str(sfile)])
     assert len(res["hs_radius"]) == 2 and res["hs_radius"][0] < res["hs_radius"][1]
+
+
+def test_pgdb_matches_reference_and_oracle(oracle):
+    """'pgdb' (process.py:291-308) through the C ABI: against what the reference returned (golden) and
+    against the oracle with the same iteration cap; both stop rules; and through ProcessTomograph."""
+    from quantpy_amd import get_engine
+    import quantpy_amd as qp
+
+    g = load_golden("pgdb")
+    for key in ("P0", "P2", "C3"):
+        n = int(g[key + "_n"])
+        povm = oracle.measurement_matrix(str(g[key + "_povm"]), n)
+        ins = g[key + "_input_states"]
+        counts = g[key + "_counts"]
+        eng = get_engine(n)
+        eng.set_povm(povm, counts[0].sum(-1).astype(float))
+        eng.process_setup(ins)
+        for stop in ("reference", "converged"):
+            got, iters = eng.pgdb(counts, n_iter=3, stop=stop, return_iters=True)
+            want = oracle.pgdb_estimate(counts, povm, list(ins), n_iter=3, stop=stop)
+            assert np.abs(got - want).max() < 1e-12, (key, stop)
+            assert np.abs(got - g[key + "_returned"]).max() < 1e-12, (key, stop)
+            assert 1 <= iters <= 3
+        batch = eng.pgdb(np.stack([counts, counts]), n_iter=2)
+        assert np.abs(batch[0] - batch[1]).max() == 0.0
+    # drop-in surface: ProcessTomograph.point_estimate('pgdb') returns a Channel
+    np.random.seed(11)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 1))
+    tmg.experiment(10000, "proj-set")
+    ch = tmg.point_estimate("pgdb", n_iter=2)
+    assert isinstance(ch, qp.Channel)
+    assert np.abs(ch.choi.matrix - np.eye(4) / 4).max() < 1e-12

@@ -215,3 +215,23 @@ def test_large_n(oracle):
     assert np.abs(oracle.lin_estimate(g["n4_counts"], a) - g["n4_lin"]).max() < 1e-12
     prob = oracle.NllProblem(g["n4_counts"], a)
     assert abs(prob.nll(g["n4_x"]) - g["n4_nll"]) < 1e-12
+
+
+def test_pgdb_against_reference(oracle):
+    """'pgdb' (process.py:291-308): the reference's first iteration piece by piece, and what it returns.
+    In every case the projected-gradient direction from the (non-CPTP, trace 1) fully mixed start is an
+    ascent direction, the backtracking loop halves alpha down to ~5.6e-17 and the estimate never moves:
+    the reference returns its starting point."""
+    g = load_golden("pgdb")
+    for key in ("P0", "P2", "C3"):
+        n = int(g[key + "_n"])
+        povm = oracle.measurement_matrix(str(g[key + "_povm"]), n)
+        ins = list(g[key + "_input_states"])
+        choi, info = oracle.pgdb_estimate(g[key + "_counts"], povm, ins, n_iter=2, return_info=True)
+        t0 = info["trace"][0]
+        assert t0["alpha"] == float(g[key + "_it0_alpha"]), key
+        assert abs(t0["dot"] - complex(g[key + "_it0_dot"])) < 1e-9 * abs(complex(g[key + "_it0_dot"])), key
+        assert abs(t0["f0"] - g[key + "_it0_nll"][0]) < 1e-12 * abs(g[key + "_it0_nll"][0]), key
+        assert np.abs(choi - g[key + "_returned"]).max() < 1e-13, key
+        conv = oracle.pgdb_estimate(g[key + "_counts"], povm, ins, n_iter=int(g[key + "_conv_cap"]), stop="converged")
+        assert np.abs(conv - g[key + "_conv_choi"]).max() < 1e-13, key

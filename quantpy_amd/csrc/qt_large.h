@@ -37,16 +37,22 @@ struct Large {
   static constexpr int NT = D;          // threads per workgroup = one trial
   static constexpr int NW = NT / 64;
   static constexpr int T = d * (d - 1) / 2;
+  // Row pitch of the d x d complex images: d + 1.  With pitch d (256 / 512 bytes) the d rows that one
+  // column is read from all start on the same LDS bank -- a 16- / 32-way conflict on every
+  // A[j][k]-over-j read (Cholesky, L L^dagger, eigenvector products); d + 1 leaves a 2-way one.
+  static constexpr int LD = d + 1;
+  static constexpr int MAT = 2 * LD * d;       // doubles per matrix image
   // LDS layout in doubles
-  static constexpr int oL = 0;                 // complex [d][d]
-  static constexpr int oVec = oL + 2 * D;      // [D]
+  static constexpr int oL = 0;                 // complex [d][LD]
+  static constexpr int oVec = oL + MAT;        // [D]
   static constexpr int oLam = oVec + D;        // [d]
   static constexpr int oRed = oLam + d;        // [32] reduction scratch
-  static constexpr int oTab = oRed + 32;       // tabT [R1][4], tabP [R1][4]
-  __host__ __device__ static int x_doubles(int M) { return (M > 2 * D ? M : 2 * D) + (M & 1); }
+  static constexpr int oRot = oRed + 32;       // Jacobi rotations of the current round: cos [d], w [d] complex
+  static constexpr int oTab = oRot + 3 * d + (d & 1);  // tabT [R1][4], tabP [R1][4]
+  __host__ __device__ static int x_doubles(int M) { return (M > MAT ? M : MAT) + (M & 1); }
   __host__ __device__ static int y_doubles(int M, int R1) {
     int y = (M / R1) * 4;  // R1^(n-1) * 4: the largest stage that lands in Y
-    if (y < 2 * D) y = 2 * D;
+    if (y < MAT) y = MAT;
     return y + (y & 1);
   }
   __host__ __device__ static size_t lds_bytes(int M, int R1, int max_iter = 0) {
@@ -54,7 +60,7 @@ struct Large {
   }
 
   struct Ctx {
-    int t, i, j;
+    int t, i, j, e;  // thread, matrix element, its slot i * LD + j in a matrix image
     double* sm;
     int M;
     ProductView pr;
@@ -66,6 +72,8 @@ struct Large {
     __device__ __forceinline__ double* vec() const { return sm + oVec; }
     __device__ __forceinline__ double* lam() const { return sm + oLam; }
     __device__ __forceinline__ double* red() const { return sm + oRed; }
+    __device__ __forceinline__ double* rot_c() const { return sm + oRot; }
+    __device__ __forceinline__ cd* rot_w() const { return reinterpret_cast<cd*>(sm + oRot + d); }
     __device__ __forceinline__ double* tabT() const { return sm + oTab; }
     __device__ __forceinline__ double* tabP() const { return sm + oTab + 4 * pr.R1; }
     __device__ __forceinline__ double* X() const { return sm + oTab + 8 * pr.R1; }
@@ -101,6 +109,7 @@ struct Large {
     c.t = threadIdx.x;
     c.i = c.t / d;
     c.j = c.t % d;
+    c.e = c.i * LD + c.j;
     c.sm = smem;
     c.M = pv.M;
     c.pr = pv.pr;
@@ -157,7 +166,7 @@ struct Large {
   __device__ static double bloch_of(const Ctx& c, const cd* m) {
     cd s{0.0, 0.0};
     for (int r = 0; r < d; ++r) {
-      const cd e = m[r * d + (r ^ c.xm)];
+      const cd e = m[r * LD + (r ^ c.xm)];
       const double sg = (__popc(r & c.zm) & 1) ? -1.0 : 1.0;
       s.re += sg * e.re;
       s.im -= sg * e.im;
@@ -249,26 +258,33 @@ struct Large {
     for (int sweep = 0; sweep < 30; ++sweep) {
       const double off = bsum(c, i != j ? a.re * a.re + a.im * a.im : 0.0);
       if (!(off > 1e-28 * nrm)) break;  // uniform: every thread holds the same sums
+      // (the rounds use the unpadded pitch d: their pivot reads A[p][q] over lanes j spread over the
+      //  banks through q = j ^ r, and padding the rows makes them collide instead)
+      // Each round has d/2 rotations and d^2 elements that need two of them each: the first d threads
+      // compute them once (index k gets the rotation of its pair, already signed for k's side) and
+      // everybody else picks up cos / w from LDS instead of redoing 2 x ~30 FP64 instructions.
+      double* rc = c.rot_c();
+      cd* rw = c.rot_w();
       for (int r = 1; r < d; ++r) {
         Ai[c.t] = a;
         Vi[c.t] = v;
         __syncthreads();
         const int pj = j ^ r, pi = i ^ r;
-        const int cp = j < pj ? j : pj, cq = j < pj ? pj : j;
-        const int rp = i < pi ? i : pi, rq = i < pi ? pi : i;
-        const double c_pp = Ai[cp * d + cp].re, c_qq = Ai[cq * d + cq].re;
-        const cd c_pq = Ai[cp * d + cq];
-        const double r_pp = Ai[rp * d + rp].re, r_qq = Ai[rq * d + rq].re;
-        const cd r_pq = Ai[rp * d + rq];
+        if (c.t < d) {
+          const int k = c.t, pk = k ^ r;
+          const int p = k < pk ? k : pk, q = k < pk ? pk : k;
+          double cs;
+          cd w;
+          rotation(Ai[p * d + p].re, Ai[q * d + q].re, Ai[p * d + q], cs, w);
+          if (k < pk) w = cd{-w.re, w.im};  // J[pk][k]: -conj(w) if k is the lower index, else w
+          rc[k] = cs;
+          rw[k] = w;
+        }
         const cd a_c = Ai[i * d + pj], a_r = Ai[pi * d + j], a_x = Ai[pi * d + pj];
         const cd v_c = Vi[i * d + pj];
         __syncthreads();
-        double cj, ci;
-        cd wj, wi;
-        rotation(c_pp, c_qq, c_pq, cj, wj);
-        rotation(r_pp, r_qq, r_pq, ci, wi);
-        if (j < pj) wj = cd{-wj.re, wj.im};
-        if (i < pi) wi = cd{-wi.re, wi.im};
+        const double cj = rc[j], ci = rc[i];
+        const cd wj = rw[j], wi = rw[i];
         const cd t0 = cadd(cscale(a, cj), cmul(a_c, wj));
         const cd t1 = cadd(cscale(a_r, cj), cmul(a_x, wj));
         a = cadd(cscale(t0, ci), cmulc(t1, wi));
@@ -277,13 +293,14 @@ struct Large {
       }
     }
     double* lam = c.lam();
-    Vi[c.t] = v;
+    Vi[c.e] = v;
     if (i == j) lam[i] = a.re;
     __syncthreads();
     cd rr{0.0, 0.0};
+#pragma unroll 4  // fully unrolled, hipcc keeps all 2 d operands live for the imaginary part and spills them
     for (int k = 0; k < d; ++k) {
       const double lc = lam[k] > eps ? lam[k] : eps;
-      const cd p = cmulc(Vi[i * d + k], Vi[j * d + k]);
+      const cd p = cmulc(Vi[i * LD + k], Vi[j * LD + k]);
       rr.re += lc * p.re;
       rr.im += lc * p.im;
     }
@@ -296,26 +313,26 @@ struct Large {
     cd* A = c.Aimg();
     cd* L = c.L();
     const int i = c.i, j = c.j;
-    A[c.t] = a;
-    L[c.t] = cd{0.0, 0.0};
+    A[c.e] = a;
+    L[c.e] = cd{0.0, 0.0};
     ok = 1;
     __syncthreads();
     for (int k = 0; k < d; ++k) {
-      const double akk = A[k * d + k].re;
+      const double akk = A[k * LD + k].re;
       if (!(akk > 0.0)) ok = 0;
       const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
-      const cd aik = A[i * d + k], ajk = A[j * d + k];
+      const cd aik = A[i * LD + k], ajk = A[j * LD + k];
       const cd lik{aik.re * rs, aik.im * rs}, ljk{ajk.re * rs, ajk.im * rs};
-      if (j == k && i >= k) L[c.t] = (i == k) ? cd{akk * rs, 0.0} : lik;
+      if (j == k && i >= k) L[c.e] = (i == k) ? cd{akk * rs, 0.0} : lik;
       if (i > k && j > k) {
         const cd p = cmulc(lik, ljk);
         a.re -= p.re;
         a.im -= p.im;
-        A[c.t] = a;
+        A[c.e] = a;
       }
       __syncthreads();
     }
-    const cd e = L[c.pi * d + c.pj];
+    const cd e = L[c.pi * LD + c.pj];
     const double x = c.pkind == 2 ? e.im : e.re;
     __syncthreads();
     return x;
@@ -324,13 +341,16 @@ struct Large {
   __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out) {
     int ok;
     double x = cholesky_param(c, r, ok);
+    QT_STAMP(3);
     const double tr = bsum(c, c.i == c.j ? r.re : 0.0);
     cd out{r.re / tr, r.im / tr};
     x = x / sqrt(tr);
     if (!ok) {  // uniform across the workgroup (one trial)
       out = psd_project(c, r, 1e-15);
+      QT_STAMP(6);
       if (xl) x = cholesky_param(c, out, ok);
       else ok = 1;
+      QT_STAMP(7);
     }
     if (xl) *xl = x;
     if (ok_out) *ok_out = ok;
@@ -349,20 +369,23 @@ struct Large {
       const int tt = (i * (i - 1)) / 2 + j;
       lij = cd{vx[d + tt], vx[d + T + tt]};
     }
-    L[c.t] = lij;
+    L[c.e] = lij;
     __syncthreads();
     cd m{0.0, 0.0};
     const int kmax = i < j ? i : j;
-    for (int k = 0; k <= kmax; ++k) m = cadd(m, cmulc(L[i * d + k], L[j * d + k]));
+    for (int k = 0; k <= kmax; ++k) m = cadd(m, cmulc(L[i * LD + k], L[j * LD + k]));
     return m;
   }
 
   // ---- a9: NLL value + exact gradient (product POVM) -------------------------------------------------
-  __device__ static void nll_grad(const Ctx& c, double xt, double& f, double& gt) {
+  // noinline: inlined into the BFGS loop, hipcc hoists the ~100 loop-invariant LDS addresses of the
+  // unrolled Pauli transforms out of that loop and, capped at 128 VGPRs by the 1024-thread workgroup,
+  // spills them (1.4 KB of scratch per thread, reloaded inside every Cholesky / Jacobi step).
+  __device__ __attribute__((noinline)) static void nll_grad(const Ctx& c, double xt, double& f, double& gt) {
     double tr;
     const cd m = build_llh(c, xt, tr);
     cd* A = c.Aimg();
-    A[c.t] = cd{m.re / tr, m.im / tr};
+    A[c.e] = cd{m.re / tr, m.im / tr};
     __syncthreads();
     const double bl = bloch_of(c, A);
     double* vec = c.vec();
@@ -399,11 +422,11 @@ struct Large {
     if (c.i == c.j) g.re -= tr_g_rho;
     g.re /= tr;
     g.im /= tr;
-    A[c.t] = g;
+    A[c.e] = g;
     __syncthreads();
     const cd* L = c.L();
     cd q{0.0, 0.0};
-    for (int k = c.pj; k < d; ++k) q = cadd(q, cmul(A[c.pi * d + k], L[k * d + c.pj]));
+    for (int k = c.pj; k < d; ++k) q = cadd(q, cmul(A[c.pi * LD + k], L[k * LD + c.pj]));
     gt = 2.0 * (c.pkind == 2 ? q.im : q.re);
     __syncthreads();
   }
@@ -495,21 +518,26 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
   const int b = blockIdx.x;
   if (b >= B) return;
   typename S::Ctx c;
+  QT_STAMP(0);
   S::make_ctx(c, smem, pv, counts + (size_t)b * pv.M);
+  QT_STAMP(1);
   int ok;
   double xk;
   if (init == 0) {
     double bl;
     const cd lin = S::lin_invert(c, bl);
+    QT_STAMP(2);
     S::make_feasible(c, lin, &xk, &ok);
   } else {
     xk = S::cholesky_param(c, cd{c.i == c.j ? 1.0 / d : 0.0, 0.0}, ok);
   }
+  QT_STAMP(8);
   double fk = 0.0, gk = 0.0;
   int kiter = 0, nfev = 0, status = ok ? 0 : 1;
   bool active = ok != 0;
   if (active) {
     S::nll_grad(c, xk, fk, gk);
+    QT_STAMP(9);
     nfev = 1;
     const double gnorm = S::bmax(c, fabs(gk));
     if (!(gnorm > gtol) || !(0 < max_iter)) active = false;
@@ -596,6 +624,7 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
   double* out = rho + ((size_t)b * D + c.t) * 2;
   out[0] = m.re / tr;
   out[1] = m.im / tr;
+  QT_STAMP(10);
   if (c.t == 0) {
     if (nit_out) nit_out[b] = kiter;
     if (nfev_out) nfev_out[b] = nfev;

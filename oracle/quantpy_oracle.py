@@ -807,3 +807,28 @@ def pgdb_estimate(counts, povm_matrix, in_states, n_iter=1000, tol=1e-10, stop="
         it = n_iter
     choi = vec2mat(v)
     return (choi, dict(iters=it, trace=trace)) if return_info else choi
+
+
+def mle_constr_estimate(counts, povm_matrix, init="lin", max_iter=100, tol=1e-3, jac="fd", return_info=False):
+    """'mle-constr' (state.py:231-253): SLSQP on the Cholesky-parametrised NLL under Tr(L L^dagger) = 1.
+    jac='fd' is the reference's call (SciPy differentiates objective and constraint by forward
+    differences); jac='analytic' hands SciPy the exact gradients, which is what the HIP-backed host code
+    does."""
+    prob = NllProblem(counts, povm_matrix)
+    x0 = mle_start(counts, povm_matrix, init)
+
+    def unit_trace(x):  # state.py:262-265
+        m = tril_vec_to_matrix(x)
+        return np.trace(m) - 1
+
+    if jac == "fd":
+        res = minimize(prob.nll, x0, constraints=[{"type": "eq", "fun": unit_trace}], method="SLSQP", tol=tol,
+                       options={"maxiter": max_iter})
+    else:
+        cons = [{"type": "eq", "fun": lambda x: float(np.dot(x, x)) - 1.0, "jac": lambda x: 2.0 * x}]
+        res = minimize(prob.nll_and_grad, x0, jac=True, constraints=cons, method="SLSQP", tol=tol,
+                       options={"maxiter": max_iter})
+    m = tril_vec_to_matrix(res.x)
+    rho = m / np.trace(m)
+    info = dict(nit=res.nit, nfev=res.nfev, status=res.status, x=res.x, fun=res.fun)
+    return (rho, info) if return_info else rho

@@ -119,11 +119,39 @@ class StateTomograph:
                 raise np.linalg.LinAlgError("starting point of the MLE is not positive definite")
             self.mle_info = info
         elif method == "mle-constr":
-            raise NotImplementedError("'mle-constr' (SLSQP) is not part of the GPU hot path")
+            rho = self._point_estimate_mle_constr(init, max_iter, tol)
         else:
             raise ValueError("Invalid value for argument `method`")
         self.reconstructed_state = Qobj(rho)
         return self.reconstructed_state
+
+    def _point_estimate_mle_constr(self, init, max_iter, tol):
+        """'mle-constr' (reference state.py:231-253): the same Cholesky-parametrised NLL minimised by
+        SciPy's SLSQP under Tr(L L^dagger) = 1.  The optimiser is the one the reference calls (its own
+        dependency, on the host); what it evaluates -- the NLL and, instead of the reference's D + 1
+        finite-difference evaluations, its exact gradient -- comes from `qt_nll_batch` on the GPU, and the
+        start point from `qt_lin_batch` / `qt_chol_param`.  Same iterates to ~1e-7, infidelity to the
+        reference's result ~1e-12 (tests/test_gpu_widening.py)."""
+        from scipy.optimize import minimize
+
+        eng = self._engine()
+        d = 2**self.state.n_qubits
+        if init == "mixed":
+            start = np.eye(d, dtype=np.complex128) / d
+        elif init == "lin":
+            start = eng.lin(self.results, physical=True)
+        else:
+            raise ValueError("Invalid value for argument `init`")
+        x0, status = eng.chol_param(start)
+        if status == 1:  # the reference fails inside scipy.linalg.cholesky here
+            raise np.linalg.LinAlgError("starting point of the MLE is not positive definite")
+        counts = self.results
+        unit_trace = {"type": "eq", "fun": lambda x: float(np.dot(x, x)) - 1.0, "jac": lambda x: 2.0 * x}
+        res = minimize(lambda x: eng.nll(x, counts, grad=True), x0, jac=True, constraints=[unit_trace], method="SLSQP",
+                       tol=tol, options={"maxiter": max_iter})
+        self.mle_info = dict(nit=res.nit, nfev=res.nfev, fun=res.fun, status=res.status)
+        m = eng.chol_unparam(res.x)
+        return m / np.trace(m)
 
     def point_estimate_batch(self, counts, method="lin", physical=True, init="lin", max_iter=100, tol=1e-3):
         """Extension: reconstruct many count tensors (B, S, K) measured with this tomograph's POVM

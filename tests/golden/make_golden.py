@@ -599,9 +599,33 @@ def gen_pgdb():
     save("pgdb", **out)
 
 
+# --------------------------------------------------------------------------------------
+# (f) 'mle-constr' (state.py:231-253): SLSQP under the unit-trace constraint
+# --------------------------------------------------------------------------------------
+def gen_constr():
+    out = {}
+    k = 0
+    for n, povm, shots, seed in ((1, "proj-set", 1000, 1), (2, "proj-set", 10000, 2), (3, "proj-set", 100000, 3),
+                                 (3, "proj-set", 1000, 4), (2, "sic", 100, 5)):
+        rho = ginibre_state(np.random.default_rng(500 + k), 2**n)
+        np.random.seed(seed)
+        t = qp.StateTomograph(qp.Qobj(rho))
+        t.experiment(shots, povm)
+        key = f"K{k}"
+        out[key + "_n"] = np.array(n)
+        out[key + "_povm"] = np.array(povm)
+        out[key + "_counts"] = t.results
+        for init in ("lin", "mixed"):
+            out[key + "_" + init] = t.point_estimate("mle-constr", init=init).matrix
+        print(f"   {key}: n={n} {povm} shots={shots}")
+        k += 1
+    out["n_cases"] = np.array(k)
+    save("constr", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large",
-                             "pgdb"]
+                             "pgdb", "constr"]
     table = {
         "operators": gen_operators,
         "states": gen_states_and_born,
@@ -613,6 +637,7 @@ if __name__ == "__main__":
         "bootstrap": gen_bootstrap,
         "large": gen_large,
         "pgdb": gen_pgdb,
+        "constr": gen_constr,
     }
     for w in which:
         print(f"[{w}]")

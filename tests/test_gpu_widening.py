@@ -126,3 +126,22 @@ def test_pgdb_matches_reference_and_oracle(oracle):
     ch = tmg.point_estimate("pgdb", n_iter=2)
     assert isinstance(ch, qp.Channel)
     assert np.abs(ch.choi.matrix - np.eye(4) / 4).max() < 1e-12
+
+
+def test_mle_constr_matches_reference(qp, oracle):
+    """StateTomograph.point_estimate('mle-constr') -- SciPy's SLSQP on the host, NLL + exact gradient from
+    qt_nll_batch -- against the reference's results (golden), both starting points."""
+    g = load_golden("constr")
+    for k in range(int(g["n_cases"])):
+        key = f"K{k}"
+        n = int(g[key + "_n"])
+        tmg = qp.StateTomograph(qp.Qobj(np.eye(2**n) / 2**n))
+        tmg.experiment(10, str(g[key + "_povm"]))
+        tmg.results = g[key + "_counts"]
+        for init in ("lin", "mixed"):
+            got = tmg.point_estimate("mle-constr", init=init)
+            assert isinstance(got, qp.Qobj)
+            assert oracle.infidelity(got.matrix, g[key + "_" + init]) < 1e-9, (key, init)
+            assert np.abs(got.matrix - g[key + "_" + init]).max() < 1e-5, (key, init)
+    with pytest.raises(ValueError):
+        tmg.point_estimate("mle-constr", init="nope")

@@ -235,3 +235,21 @@ def test_pgdb_against_reference(oracle):
         assert np.abs(choi - g[key + "_returned"]).max() < 1e-13, key
         conv = oracle.pgdb_estimate(g[key + "_counts"], povm, ins, n_iter=int(g[key + "_conv_cap"]), stop="converged")
         assert np.abs(conv - g[key + "_conv_choi"]).max() < 1e-13, key
+
+
+def test_mle_constr_against_reference(oracle):
+    """'mle-constr' (state.py:231-253): the oracle's SLSQP call reproduces the reference's results, and
+    with exact gradients (what the HIP-backed host code hands SciPy) stays within 1e-9 infidelity."""
+    g = load_golden("constr")
+    for k in range(int(g["n_cases"])):
+        key = f"K{k}"
+        n = int(g[key + "_n"])
+        povm = oracle.measurement_matrix(str(g[key + "_povm"]), n)
+        for init in ("lin", "mixed"):
+            want = g[key + "_" + init]
+            got = oracle.mle_constr_estimate(g[key + "_counts"], povm, init=init)
+            # forward differences with h = 1.5e-8 turn the last-bit differences between two NLL
+            # implementations into ~1e-8 of gradient noise, so the iterates agree to ~1e-7, not to rounding
+            assert np.abs(got - want).max() < 1e-5 and oracle.infidelity(got, want) < 1e-9, (key, init)
+            exact = oracle.mle_constr_estimate(g[key + "_counts"], povm, init=init, jac="analytic")
+            assert oracle.infidelity(exact, want) < 1e-9, (key, init)

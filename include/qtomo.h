@@ -130,6 +130,13 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
 /* dist[b] = sqrt(|Tr((rho_b - centre)^2)|) / sqrt(2), set to 0 below 1e-15 */
 int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, int B, double* dist, int flags);
 
+/* Metropolis-Hastings chains on the Cholesky parameters (mhmc.py:80-119 with `normalized_update`, used by
+ * MHMCStateInterval, interval.py:735-750): C independent chains (the reference runs one), each on its
+ * own counts[c][S][K]; x_init[C][D]; proposal increments deltas[C][T][D] and uniforms[C][T] drawn by the
+ * caller (host RNG, reference order); chain[C][T][D] = state after every step, accepted[C][T].  n <= 3. */
+int qt_mhmc_state(qt_handle_t* h, const int64_t* counts, int C, const double* x_init, const double* deltas,
+                  const double* uniforms, int T, double step, double* chain, int32_t* accepted, int flags);
+
 /* ---- a11-a15: quantpy/tomography/process.py -------------------------------------------------- */
 /* Process tomography of an n-qubit channel (handle created with n_qubits = n, n <= 2 here).
  * qt_process_setup: input states in_states[D][d][d][2] (process.py:79), the weighted POVM of

@@ -832,3 +832,41 @@ def mle_constr_estimate(counts, povm_matrix, init="lin", max_iter=100, tol=1e-3,
     rho = m / np.trace(m)
     info = dict(nit=res.nit, nfev=res.nfev, status=res.status, x=res.x, fun=res.fun)
     return (rho, info) if return_info else rho
+
+
+def mhmc_state_chain(counts, povm_matrix, x_init, deltas, uniforms, step):
+    """The Metropolis-Hastings chain of mhmc.py:80-119 with `normalized_update` (mhmc.py:116-119) and
+    target -nll (interval.py:739): returns (states after every step, accepted flags)."""
+    prob = NllProblem(counts, povm_matrix)
+    x = np.array(x_init, dtype=float)
+    f = prob.nll(x)
+    chain = np.empty((len(deltas), len(x)))
+    acc = np.zeros(len(deltas), dtype=np.int32)
+    for t, (dl, u) in enumerate(zip(deltas, uniforms)):
+        xp = x + step * dl
+        xp = xp / np.linalg.norm(xp)
+        fp = prob.nll(xp)
+        if u <= np.exp(f - fp):
+            x, f = xp, fp
+            acc[t] = 1
+        chain[t] = x
+    return chain, acc
+
+
+def mhmc_state_interval(counts, povm_matrix, state_matrix, n_points, step, burn_steps, thinning=1):
+    """MHMCStateInterval.setup (interval.py:735-750) with the reference's order of random draws
+    (mhmc.py:61-62, 88-89: rvs then rand, burn-in first).  Returns (sorted HS distances, samples, rate)."""
+    from scipy.stats import multivariate_normal
+
+    dim = povm_matrix.shape[-1]
+    jump = multivariate_normal(mean=np.zeros(dim))
+    x0 = matrix_to_tril_vec(state_matrix)
+    db = jump.rvs(size=burn_steps).reshape(burn_steps, dim)
+    ub = np.random.rand(burn_steps)
+    total = n_points * thinning
+    ds = jump.rvs(size=total).reshape(total, dim)
+    us = np.random.rand(total)
+    chain, acc = mhmc_state_chain(counts, povm_matrix, x0, np.concatenate([db, ds]), np.concatenate([ub, us]), step)
+    samples = chain[burn_steps::thinning][:n_points]
+    dist = np.sort([hs_dst(tril_vec_to_matrix(v), state_matrix) for v in samples])
+    return dist, samples, float(acc[burn_steps:].mean())

@@ -20,6 +20,7 @@ from .tomography.interval import (  # noqa: F401
     BootstrapProcessInterval,
     BootstrapStateInterval,
     ConfidenceInterval,
+    MHMCStateInterval,
     MomentInterval,
 )
 from .tomography.process import ProcessTomograph  # noqa: F401

@@ -45,6 +45,7 @@ SIGNATURES = {
     "qt_chol_unparam": (_c_int, [_vp, _vp, _c_int, _vp, _c_int]),
     "qt_nll_batch": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _vp, _c_int]),
     "qt_mle_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, _vp, _vp, _vp, _vp, _c_int]),
+    "qt_mhmc_state": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _c_int]),
     "qt_hs_dist_batch": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int]),
     "qt_process_setup": (_c_int, [_vp, _vp, _c_int]),
     "qt_process_get_operators": (_c_int, [_vp, _vp, _vp, _c_int]),

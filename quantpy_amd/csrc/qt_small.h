@@ -884,7 +884,8 @@ struct Small {
   }
 
   // ---- a9: NLL value and exact gradient at x (image = Aw).  Needs freq[] loaded.  Leaves L in Bm().
-  __device__ static void nll_grad(const Ctx& c, double xl, double& f, double& gl, cd* rho_l = nullptr) {
+  __device__ static void nll_grad(const Ctx& c, double xl, double& f, double& gl, cd* rho_l = nullptr,
+                                  bool want_grad = true) {
     double tr;
     QT_STAMP(11);
     const cd m = build_llh(c, xl, tr);
@@ -928,6 +929,7 @@ struct Small {
       f = -gsum<G>(fpart);
       wave_sync();
       QT_STAMP(15);
+      if (!want_grad) return;  // (uniform) the Metropolis chain only needs the value
       wl = prod_backward(c, c.tabT(), rb);
       QT_STAMP(16);
     } else {
@@ -941,6 +943,7 @@ struct Small {
       }
       f = -gsum<G>(fpart);
       wave_sync();
+      if (!want_grad) return;
       // w = A'^T r ;  G = -sum_k w_k P_k ;  Gt = (G - Tr(G rho) I) / t
       wl = col_dot(c, c.pv.Aw, rb);
     }
@@ -1336,6 +1339,50 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
     fk = 0.0;
   }
   bfgs_iterate<NQ, ALDS>(c, iterate, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out);
+}
+
+// Metropolis-Hastings chain on the Cholesky parameters (reference mhmc.py:80-119 with
+// `normalized_update`, interval.py:735-750): one chain per lane group, the proposal increments and the
+// uniforms drawn on the host in the reference's order.  Step t:
+//   x' = (x + step * delta_t) / ||x + step * delta_t||,  alpha = exp(nll(x) - nll(x')),  accept iff u_t <= alpha.
+// chain[c][t][:] = the state AFTER step t, accepted[c][t] = 0 / 1.
+template <int NQ, bool ALDS>
+__global__ void __launch_bounds__(256) k_mhmc_state(PovmView pv, const int64_t* __restrict__ counts, int C,
+                                                    const double* __restrict__ x_init, const double* __restrict__ deltas,
+                                                    const double* __restrict__ uniforms, int T_steps, double step,
+                                                    double* __restrict__ chain, int32_t* __restrict__ accepted) {
+  using S = Small<NQ, ALDS>;
+  constexpr int D = S::D, G = S::G;
+  extern __shared__ double smem[];
+  typename S::Ctx c;
+  S::make_ctx(c, smem, pv);
+  bool live;
+  const int b = S::trial_index(C, &live);
+  const int bb = live ? b : C - 1;
+  S::load_image(c, pv.Aw);
+  S::load_freq(c, counts + (size_t)bb * pv.M);
+  double x = x_init[(size_t)bb * D + c.l];
+  double f, unused;
+  S::nll_grad(c, x, f, unused, nullptr, false);
+  const double* dl = deltas + (size_t)bb * T_steps * D + c.l;
+  const double* un = uniforms + (size_t)bb * T_steps;
+  for (int t = 0; t < T_steps; ++t) {
+    const double xp = fma(step, dl[(size_t)t * D], x);
+    const double nrm = sqrt(gsum<G>(xp * xp));
+    const double xn = xp / nrm;
+    double fn;
+    S::nll_grad(c, xn, fn, unused, nullptr, false);
+    const double alpha = exp(f - fn);
+    const bool acc = un[t] <= alpha;  // false for a NaN alpha, like the reference's comparison
+    if (acc) {
+      x = xn;
+      f = fn;
+    }
+    if (live) {
+      chain[((size_t)b * T_steps + t) * D + c.l] = x;
+      if (c.l == 0) accepted[(size_t)b * T_steps + t] = acc ? 1 : 0;
+    }
+  }
 }
 
 }  // namespace qt

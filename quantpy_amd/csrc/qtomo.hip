@@ -700,6 +700,31 @@ int qt_nll_batch(qt_handle_t* h, const double* x, const int64_t* counts, int B, 
   return finish(h, flags);
 }
 
+int qt_mhmc_state(qt_handle_t* h, const int64_t* counts, int C, const double* x_init, const double* deltas,
+                  const double* uniforms, int T, double step, double* chain, int32_t* accepted, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (int r = need_povm(h)) return r;
+  if (C < 0 || T < 0 || (C > 0 && T > 0 && (!counts || !x_init || !deltas || !uniforms || !chain || !accepted)))
+    return fail(QT_ERR_ARG, "bad mhmc_state arguments");
+  if (h->nq > 3) return fail(QT_ERR_UNSUPPORTED, "qt_mhmc_state supports n_qubits 1..3");
+  if (C == 0 || T == 0) return 0;
+  const int64_t* dc;
+  const double *dx, *dd, *du;
+  double* dch;
+  int32_t* dacc;
+  const size_t nel = (size_t)C * T * h->D;
+  if (int r = stage_in(h, h->in0, counts, (size_t)C * h->M, flags, &dc)) return r;
+  if (int r = stage_in(h, h->in1, x_init, (size_t)C * h->D, flags, &dx)) return r;
+  if (int r = stage_in(h, h->out2, deltas, nel, flags, &dd)) return r;
+  if (int r = stage_in(h, h->out3, uniforms, (size_t)C * T, flags, &du)) return r;
+  if (int r = stage_out(h, h->out0, chain, nel, flags, &dch)) return r;
+  if (int r = stage_out(h, h->out1, accepted, (size_t)C * T, flags, &dacc)) return r;
+  QT_LAUNCH_SMALL(qt::k_mhmc_state, h->M, C, (h->view(), dc, C, dx, dd, du, T, step, dch, dacc));
+  if (int r = fetch_out(h, dch, chain, nel, flags)) return r;
+  if (int r = fetch_out(h, dacc, accepted, (size_t)C * T, flags)) return r;
+  return finish(h, flags);
+}
+
 int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol, double* rho,
                  int32_t* nit, int32_t* nfev, double* fun, int32_t* status, int flags) {
   if (int r = check_handle(h)) return r;

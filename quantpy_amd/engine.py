@@ -335,6 +335,21 @@ class Engine:
             return rho, dict(nit=nit, nfev=nfev, fun=fun, status=status)
         return rho
 
+    def mhmc_state(self, counts, x_init, deltas, uniforms, step):
+        """Metropolis-Hastings chain(s) of mhmc.py on the Cholesky parameters: counts (S, K) or (C, S, K),
+        x_init (D,) / (C, D), deltas (T, D) / (C, T, D), uniforms (T,) / (C, T) -> (chain (.., T, D), accepted (.., T))."""
+        c, single = self._counts(counts)
+        nchain = c.shape[0]
+        x0 = _f64(x_init).reshape(nchain, self.D)
+        dl = _f64(deltas).reshape(nchain, -1, self.D)
+        t = dl.shape[1]
+        un = _f64(uniforms).reshape(nchain, t)
+        chain = np.empty((nchain, t, self.D))
+        acc = np.zeros((nchain, t), dtype=np.int32)
+        self._chk(self.lib.qt_mhmc_state(self._h, _ptr(c), nchain, _ptr(x0), _ptr(dl), _ptr(un), t, float(step),
+                                         _ptr(chain), _ptr(acc), _capi.QT_HOST_PTR))
+        return (chain[0], acc[0]) if single else (chain, acc)
+
     def mle_dev(self, counts, rho, init="lin", max_iter=100, tol=1e-3, nit=None, nfev=None, fun=None, status=None):
         self._chk(self.lib.qt_mle_batch(self._h, _ptr(counts), counts.shape[0],
                                         _capi.QT_INIT_LIN if init == "lin" else _capi.QT_INIT_MIXED, int(max_iter),

@@ -2,6 +2,7 @@ from .interval import (  # noqa: F401
     BootstrapProcessInterval,
     BootstrapStateInterval,
     ConfidenceInterval,
+    MHMCStateInterval,
     MomentInterval,
 )
 from .process import ProcessTomograph  # noqa: F401

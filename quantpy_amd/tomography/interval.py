@@ -180,6 +180,57 @@ class BootstrapStateInterval(ConfidenceInterval):
         self._finish(self.boot_dist)
 
 
+class MHMCStateInterval(ConfidenceInterval):
+    """Metropolis-Hastings samples of the likelihood on the Cholesky parameters around the point estimate
+    (reference interval.py:689-750, mhmc.py): distances tmg.dst(sample, state), sorted.
+    The random numbers are drawn here exactly as the reference draws them -- proposal increments from
+    scipy's frozen `multivariate_normal(zeros(4^n))`, then `numpy.random.rand`, first for the burn-in,
+    then for the samples -- and the chain itself (one likelihood evaluation per step, inherently serial)
+    runs in one launch of `qt_mhmc_state`."""
+
+    def __init__(self, tmg, n_points=1000, step=0.01, burn_steps=1000, thinning=1, warm_start=False,
+                 use_new_estimate=False, state=None, verbose=False):
+        super().__init__(tmg, **_pop_hidden_keys(locals()))
+
+    def setup(self):
+        from scipy.stats import multivariate_normal
+
+        if self.mode == Mode.CHANNEL:
+            raise NotImplementedError("This interval works only for state tomography")
+        tmg = self.tmg
+        if not self.use_new_estimate:
+            self.state = tmg.reconstructed_state
+        elif self.state is None:
+            self.state = tmg.point_estimate(method="mle", physical=True)
+        eng = tmg._engine()
+        dim = 4**tmg.state.n_qubits
+        if not (self.warm_start and hasattr(self, "_x_t")):
+            x0, status = eng.chol_param(np.asarray(self.state.matrix, dtype=np.complex128))
+            if status == 1:  # the reference fails inside scipy.linalg.cholesky here
+                raise np.linalg.LinAlgError("the state the chain starts from is not positive definite")
+            self._x_t, self._burned = x0, False
+        jump = multivariate_normal(mean=np.zeros(dim))
+        parts = []
+        if not self._burned:
+            parts.append((jump.rvs(size=self.burn_steps).reshape(self.burn_steps, dim), np.random.rand(self.burn_steps)))
+        total = self.n_points * self.thinning
+        parts.append((jump.rvs(size=total).reshape(total, dim), np.random.rand(total)))
+        deltas = np.concatenate([p[0] for p in parts])
+        uniforms = np.concatenate([p[1] for p in parts])
+        chain, accepted = eng.mhmc_state(tmg.results, self._x_t, deltas, uniforms, self.step)
+        skip = 0 if self._burned else self.burn_steps
+        self._burned = True
+        self._x_t = chain[-1].copy() if len(chain) else self._x_t
+        self.samples = chain[skip::self.thinning][: self.n_points]
+        self.acceptance_rate = float(accepted[skip:].mean()) if total else 0.0
+        mats = eng.chol_unparam(self.samples)
+        if tmg.dst is hs_dst:
+            dist = eng.hs_dist(mats, np.asarray(self.state.matrix, dtype=np.complex128))
+        else:
+            dist = np.array([tmg.dst(m, self.state.matrix) for m in mats], dtype=np.float64)
+        self._finish(dist)
+
+
 class BootstrapProcessInterval(ConfidenceInterval):
     """Parametric bootstrap of a process tomography around `channel` (default: the reconstructed
     channel): resampled counts for every input state, batched Choi reconstruction."""

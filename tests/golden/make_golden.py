@@ -623,9 +623,45 @@ def gen_constr():
     save("constr", **out)
 
 
+# --------------------------------------------------------------------------------------
+# (f) MHMCStateInterval (interval.py:689-750, mhmc.py)
+# --------------------------------------------------------------------------------------
+def gen_mhmc():
+    out = {}
+    cls = np.array([0.1, 0.5, 0.9, 0.99])
+    k = 0
+    for n, povm, shots, seed, n_points, burn, step, thin in ((1, "proj-set", 1000, 1, 150, 60, 0.01, 1),
+                                                             (2, "proj-set", 10000, 2, 120, 40, 0.005, 2),
+                                                             (3, "proj-set", 100000, 3, 100, 30, 0.001, 1)):
+        rho = ginibre_state(np.random.default_rng(700 + k), 2**n)
+        np.random.seed(seed)
+        t = qp.StateTomograph(qp.Qobj(rho))
+        t.experiment(shots, povm)
+        est = t.point_estimate("mle")
+        key = f"H{k}"
+        np.random.seed(100 + seed)
+        iv = qp.MHMCStateInterval(t, n_points=n_points, step=step, burn_steps=burn, thinning=thin)
+        radii = iv(cls)[0]
+        out[key + "_n"] = np.array(n)
+        out[key + "_povm"] = np.array(povm)
+        out[key + "_counts"] = t.results
+        out[key + "_state"] = est.matrix
+        out[key + "_args"] = np.array([n_points, burn, thin])
+        out[key + "_step"] = np.array(step)
+        out[key + "_rng_seed"] = np.array(100 + seed)
+        out[key + "_radii"] = radii
+        out[key + "_all_dist"] = iv.cl_to_dist(np.linspace(0, 1, n_points))
+        out[key + "_final_x"] = iv.chain.x_t
+        print(f"   {key}: n={n} radii {radii}")
+        k += 1
+    out["n_cases"] = np.array(k)
+    out["conf_levels"] = cls
+    save("mhmc", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large",
-                             "pgdb", "constr"]
+                             "pgdb", "constr", "mhmc"]
     table = {
         "operators": gen_operators,
         "states": gen_states_and_born,
@@ -638,6 +674,7 @@ if __name__ == "__main__":
         "large": gen_large,
         "pgdb": gen_pgdb,
         "constr": gen_constr,
+        "mhmc": gen_mhmc,
     }
     for w in which:
         print(f"[{w}]")

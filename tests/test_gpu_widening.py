@@ -145,3 +145,41 @@ def test_mle_constr_matches_reference(qp, oracle):
             assert np.abs(got.matrix - g[key + "_" + init]).max() < 1e-5, (key, init)
     with pytest.raises(ValueError):
         tmg.point_estimate("mle-constr", init="nope")
+
+
+def test_mhmc_state_interval_matches_reference(qp, oracle):
+    """MHMCStateInterval through qt_mhmc_state: the reference's radii (golden, same seed), the oracle's
+    chain state by state, and warm_start continuing the chain."""
+    g = load_golden("mhmc")
+    for k in range(int(g["n_cases"])):
+        key = f"H{k}"
+        n = int(g[key + "_n"])
+        povm_name = str(g[key + "_povm"])
+        n_points, burn, thin = (int(v) for v in g[key + "_args"])
+        step = float(g[key + "_step"])
+        tmg = qp.StateTomograph(qp.Qobj(np.eye(2**n) / 2**n))
+        tmg.experiment(10, povm_name)
+        tmg.results = g[key + "_counts"]
+        tmg.reconstructed_state = qp.Qobj(g[key + "_state"])
+        np.random.seed(int(g[key + "_rng_seed"]))
+        iv = qp.MHMCStateInterval(tmg, n_points=n_points, step=step, burn_steps=burn, thinning=thin)
+        radii = iv(g["conf_levels"])[0]
+        assert np.abs(radii - g[key + "_radii"]).max() < 1e-10, (key, radii, g[key + "_radii"])
+        assert np.abs(iv.cl_to_dist(np.linspace(0, 1, n_points)) - g[key + "_all_dist"]).max() < 1e-10, key
+        np.random.seed(int(g[key + "_rng_seed"]))
+        _, samples, rate = oracle.mhmc_state_interval(g[key + "_counts"], oracle.measurement_matrix(povm_name, n),
+                                                      g[key + "_state"], n_points, step, burn, thin)
+        assert np.abs(iv.samples - samples).max() < 1e-12, key
+        assert abs(iv.acceptance_rate - rate) < 1e-12
+    # warm start: the second call continues from the last state without a new burn-in
+    np.random.seed(5)
+    iv = qp.MHMCStateInterval(tmg, n_points=20, step=0.001, burn_steps=10, warm_start=True)
+    iv.setup()
+    last = iv._x_t.copy()
+    iv.setup()
+    assert iv._burned and not np.array_equal(last, iv._x_t)
+    with pytest.raises(NotImplementedError):
+        np.random.seed(11)
+        ptm = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 1))
+        ptm.experiment(100, "proj-set")
+        qp.MHMCStateInterval(ptm).setup()

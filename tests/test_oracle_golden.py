@@ -253,3 +253,21 @@ def test_mle_constr_against_reference(oracle):
             assert np.abs(got - want).max() < 1e-5 and oracle.infidelity(got, want) < 1e-9, (key, init)
             exact = oracle.mle_constr_estimate(g[key + "_counts"], povm, init=init, jac="analytic")
             assert oracle.infidelity(exact, want) < 1e-9, (key, init)
+
+
+def test_mhmc_state_interval_against_reference(oracle):
+    """MHMCStateInterval (interval.py:689-750, mhmc.py): same global RNG seed, same order of draws -> the
+    oracle's chain ends where the reference's ended and gives the same distance quantiles."""
+    g = load_golden("mhmc")
+    for k in range(int(g["n_cases"])):
+        key = f"H{k}"
+        n = int(g[key + "_n"])
+        povm = oracle.measurement_matrix(str(g[key + "_povm"]), n)
+        n_points, burn, thin = (int(v) for v in g[key + "_args"])
+        np.random.seed(int(g[key + "_rng_seed"]))
+        dist, samples, rate = oracle.mhmc_state_interval(g[key + "_counts"], povm, g[key + "_state"], n_points,
+                                                        float(g[key + "_step"]), burn, thin)
+        assert np.abs(dist - g[key + "_all_dist"]).max() < 1e-12, key
+        q = np.interp(g["conf_levels"], np.linspace(0, 1, len(dist)), dist)
+        assert np.abs(q - g[key + "_radii"]).max() < 1e-12, key
+        assert 0.0 < rate <= 1.0

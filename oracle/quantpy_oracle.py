@@ -822,8 +822,12 @@ def mle_constr_estimate(counts, povm_matrix, init="lin", max_iter=100, tol=1e-3,
         return np.trace(m) - 1
 
     if jac == "fd":
-        res = minimize(prob.nll, x0, constraints=[{"type": "eq", "fun": unit_trace}], method="SLSQP", tol=tol,
-                       options={"maxiter": max_iter})
+        import warnings
+
+        with warnings.catch_warnings():  # the reference's constraint returns a complex number (np.trace - 1)
+            warnings.simplefilter("ignore")
+            res = minimize(prob.nll, x0, constraints=[{"type": "eq", "fun": unit_trace}], method="SLSQP", tol=tol,
+                           options={"maxiter": max_iter})
     else:
         cons = [{"type": "eq", "fun": lambda x: float(np.dot(x, x)) - 1.0, "jac": lambda x: 2.0 * x}]
         res = minimize(prob.nll_and_grad, x0, jac=True, constraints=cons, method="SLSQP", tol=tol,

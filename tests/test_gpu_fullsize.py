@@ -1,0 +1,98 @@
+"""GPU: size-independent properties at the full sizes of BASELINE.json's configs (C2: n = 3, B = 1000 and
+the saturated 65 536-trial batch; C5: n = 5), where running the oracle trial by trial would take minutes:
+round trips through exact Born probabilities, linearity of the linear inversion, equivariance under a
+permutation of the batch, independence of the batch size (the small-batch fused kernel and the split
+start + BFGS kernels must agree), and the invariants of every returned state."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ginibre(rng, d, rank=None):
+    g = rng.standard_normal((d, rank or d)) + 1j * rng.standard_normal((d, rank or d))
+    r = g @ g.conj().T
+    return r / np.trace(r).real
+
+
+def _exact_counts(oracle, povm, rho, n_shots):
+    d = rho.shape[0]
+    p = np.einsum("skd,d->sk", povm, oracle.bloch_from_matrix(rho)) * d
+    c = np.rint(p * n_shots).astype(np.int64)
+    for s in range(c.shape[0]):
+        c[s, np.argmax(c[s])] += int(n_shots) - c[s].sum()
+    return c
+
+
+def test_c2_full_batch_properties(oracle):
+    import quantpy_amd as qp
+    from quantpy_amd.tomography.state import simulate_counts
+
+    n, d, B = 3, 8, 1000
+    rng = np.random.default_rng(2024)
+    povm = qp.generate_measurement_matrix("proj-set", n)
+    shots = np.ones(povm.shape[0]) * 100000
+    eng = qp.get_engine(n)
+    eng.set_povm(povm, shots)
+    # --- round trip: exact probabilities of B different states -> the states (linear inversion is exact)
+    states = np.stack([_ginibre(rng, d) for _ in range(B)])
+    exact = np.stack([_exact_counts(oracle, np.asarray(povm), r, 10**12) for r in states])
+    eng.set_povm(povm, np.ones(povm.shape[0]) * 1e12)
+    back = eng.lin(exact, physical=False)
+    assert np.abs(back - states).max() < 1e-10
+    assert np.abs(eng.lin(exact, physical=True) - states).max() < 1e-10  # already physical: the clip is the identity
+    # --- linearity of the inversion in the counts (same totals): lin(a + b) = (lin(a) + lin(b)) / 2
+    eng.set_povm(povm, np.ones(povm.shape[0]) * 2e12)
+    both = eng.lin(exact[: B // 2] + exact[B // 2:], physical=False)
+    assert np.abs(both - 0.5 * (back[: B // 2] + back[B // 2:])).max() < 1e-12
+    # --- sampled counts at the C2 shot number: invariants of every estimate, equivariance, batch size
+    eng.set_povm(povm, shots)
+    np.random.seed(99)
+    truth = _ginibre(rng, d)
+    counts = np.stack([simulate_counts(povm, qp.Qobj(truth).bloch, shots) for _ in range(B)])
+    rho, info = eng.mle(counts, return_info=True)
+    assert np.all(info["status"] == 0)
+    assert np.abs(np.trace(rho, axis1=1, axis2=2) - 1).max() < 1e-13
+    assert np.abs(rho - rho.conj().transpose(0, 2, 1)).max() < 1e-15
+    assert np.linalg.eigvalsh(rho).min() > -1e-15
+    lin = eng.lin(counts, physical=True)
+    x_lin, st = eng.chol_param(lin)
+    x_mle, _ = eng.chol_param(rho)
+    ok = st == 0
+    f_lin = eng.nll(x_lin[ok], counts[ok], grad=False)
+    f_mle = eng.nll(x_mle[ok], counts[ok], grad=False)
+    assert np.all(f_mle <= f_lin + 1e-12)  # BFGS never returns a worse likelihood than its start
+    perm = rng.permutation(B)
+    rho_p = eng.mle(counts[perm])
+    assert np.array_equal(rho_p, rho[perm])  # bit for bit: no cross-trial coupling
+    big = np.concatenate([counts] * 66)[:65536]  # the split start + BFGS kernels
+    rho_big = eng.mle(big)
+    assert np.abs(rho_big[:B] - rho).max() < 1e-13
+    assert np.abs(rho_big[B:2 * B] - rho).max() < 1e-13
+
+
+def test_c5_size_properties(oracle):
+    import quantpy_amd as qp
+    from quantpy_amd.tomography.state import simulate_counts
+
+    n, d, B = 5, 32, 24
+    rng = np.random.default_rng(55)
+    povm = qp.generate_measurement_matrix("proj-set", n)
+    eng = qp.get_engine(n)
+    states = np.stack([_ginibre(rng, d) for _ in range(4)])
+    pv = np.asarray(povm)
+    exact = np.stack([_exact_counts(oracle, pv, r, 10**13) for r in states])
+    eng.set_povm(povm, np.ones(povm.shape[0]) * 1e13)
+    assert np.abs(eng.lin(exact, physical=False) - states).max() < 1e-9
+    shots = np.ones(povm.shape[0]) * 10**6
+    eng.set_povm(povm, shots)
+    np.random.seed(5)
+    few = np.stack([simulate_counts(povm, qp.Qobj(states[0]).bloch, shots) for _ in range(6)])
+    counts = np.concatenate([few] * (B // 6))
+    rho, info = eng.mle(counts, return_info=True)
+    assert np.all(info["status"] == 0)
+    assert np.abs(np.trace(rho, axis1=1, axis2=2) - 1).max() < 1e-12
+    assert np.linalg.eigvalsh(rho).min() > -1e-14
+    assert np.array_equal(rho[:6], rho[6:12])  # identical inputs, identical bits, whichever CU ran them
+    perm = rng.permutation(B)
+    assert np.array_equal(eng.mle(counts[perm]), rho[perm])

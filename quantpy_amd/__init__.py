@@ -20,8 +20,15 @@ from .tomography.interval import (  # noqa: F401
     BootstrapProcessInterval,
     BootstrapStateInterval,
     ConfidenceInterval,
+    HolderInterval,
+    MHMCProcessInterval,
     MHMCStateInterval,
+    MomentFidelityProcessInterval,
+    MomentFidelityStateInterval,
     MomentInterval,
+    PolytopeProcessInterval,
+    PolytopeStateInterval,
+    SugiyamaInterval,
 )
 from .tomography.process import ProcessTomograph  # noqa: F401
 from .tomography.state import StateTomograph  # noqa: F401

@@ -231,6 +231,109 @@ class MHMCStateInterval(ConfidenceInterval):
         self._finish(dist)
 
 
+class SugiyamaInterval(ConfidenceInterval):
+    """Hoeffding-type interval of Sugiyama et al., arXiv:1306.4191 (reference interval.py:219-265): closed
+    form in the left inverse of the rescaled POVM matrix (computed on the GPU, `qt_left_inverse`)."""
+
+    def __init__(self, tmg, n_points=1000, max_confidence=0.999):
+        super().__init__(tmg, **_pop_hidden_keys(locals()))
+
+    def setup(self):
+        from ..geometry import if_dst, trace_dst
+
+        if self.mode == Mode.CHANNEL:
+            raise NotImplementedError("Sugiyama interval works only for state tomography")
+        tmg = self.tmg
+        dim = 2**tmg.state.n_qubits
+        dist = np.linspace(0, 1, self.n_points)
+        settings, outcomes, width = tmg.povm_matrix.shape
+        scaled = np.reshape(np.asarray(tmg.povm_matrix), (-1, width)) * dim / np.sqrt(2 * dim)
+        inverse = get_engine(tmg.state.n_qubits).left_inverse_of(scaled).reshape(-1, settings, outcomes)
+        ratios = tmg.n_measurements.sum() / tmg.n_measurements
+        spread = np.max(inverse, axis=-1) - np.min(inverse, axis=-1)
+        c_alpha = np.sum(spread**2 * ratios[None, :], axis=-1) + self.EPS
+        if tmg.dst == hs_dst:
+            b = 8 / (dim**2 - 1)
+        elif tmg.dst == trace_dst:
+            b = 16 / (dim**2 - 1) / dim
+        elif tmg.dst == if_dst:
+            b = 4 / (dim**2 - 1) / dim
+        else:
+            raise NotImplementedError("Unsupported distance")
+        conf_levels = 1 - 2 * np.sum(np.exp(-b * dist[:, None] ** 2 * np.sum(tmg.n_measurements) / c_alpha[None, :]),
+                                     axis=1)
+        self.cl_to_dist = interp1d(conf_levels, dist)
+
+
+class HolderInterval(ConfidenceInterval):
+    """Process interval assembled from one state interval per input state (reference interval.py:421-539):
+    conf_level^(number of inputs) and sqrt(sum_ij |c_i . conj(c_j)| delta_i delta_j) over the
+    coordinates c of the single-entry matrices in the input basis.  `kind` in {'mhmc', 'bootstrap',
+    'sugiyama'}; as in the reference, the default 'wang' (and 'boot') is rejected by `setup` with a
+    ValueError and 'moment' fails on MomentInterval's signature."""
+
+    def __init__(self, tmg, n_points=1000, kind="wang", max_confidence=0.999, method="lin", method_boot="lin",
+                 physical=True, init="lin", tol=1e-3, max_iter=100, step=0.01, burn_steps=1000, thinning=1):
+        super().__init__(tmg, **_pop_hidden_keys(locals()))
+
+    def __call__(self, conf_levels=None):
+        if conf_levels is None:
+            conf_levels = np.linspace(1e-3, 1 - 1e-3, 1000)
+        if not hasattr(self, "intervals"):
+            self.setup()
+        results = [interval(conf_levels) for interval in self.intervals]
+        deltas = np.asarray([r[0] for r in results])
+        conf_levels = results[0][1] ** self.tmg.input_basis.dim
+        entries = self.tmg._decomposed_single_entries
+        coef = np.abs(np.einsum("ij,ik->jk", entries, entries.conj()))
+        dist = np.sqrt(np.einsum("ik,jk,ij->k", deltas, deltas, coef))
+        return dist, conf_levels
+
+    def setup(self):
+        if self.mode == Mode.STATE:
+            raise NotImplementedError("Holder interval works only for process tomography")
+        parts = self.tmg.tomographs
+        if self.kind == "moment":
+            self.intervals = [MomentInterval(t, self.n_points, self.max_confidence) for t in parts]  # TypeError, as there
+        elif self.kind == "mhmc":
+            self.intervals = [MHMCStateInterval(t, self.n_points, self.step, self.burn_steps, self.thinning) for t in parts]
+        elif self.kind == "bootstrap":
+            self.intervals = [BootstrapStateInterval(t, self.n_points, self.method, physical=self.physical, init=self.init,
+                                                     tol=self.tol, max_iter=self.max_iter) for t in parts]
+        elif self.kind == "sugiyama":
+            self.intervals = [SugiyamaInterval(t, self.n_points, self.max_confidence) for t in parts]
+        else:
+            raise ValueError("Incorrect value for argument `kind`.")
+        for interval in self.intervals:
+            interval.setup()
+
+
+def _needs_cvxopt(name, lines):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError(f"{name} (reference interval.py:{lines}) poses a cone / linear program for cvxopt; "
+                                  "that solver is outside the tomography hot path and is not provided")
+
+    return type(name, (ConfidenceInterval,), {"__init__": __init__, "setup": lambda self: None,
+                                              "__doc__": f"Placeholder: the reference's {name} needs cvxopt."})
+
+
+MomentFidelityStateInterval = _needs_cvxopt("MomentFidelityStateInterval", "113-160")
+MomentFidelityProcessInterval = _needs_cvxopt("MomentFidelityProcessInterval", "163-216")
+PolytopeStateInterval = _needs_cvxopt("PolytopeStateInterval", "268-335")
+PolytopeProcessInterval = _needs_cvxopt("PolytopeProcessInterval", "338-418")
+
+
+class MHMCProcessInterval(ConfidenceInterval):
+    """Not provided: the reference's chain (interval.py:763-850) projects every proposal onto the CPTP set
+    with a full Dykstra iteration (`_cptp_update_rule`, process.py:279-281)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("MHMCProcessInterval is not provided (one Dykstra CPTP projection per chain step)")
+
+    def setup(self):
+        pass
+
+
 class BootstrapProcessInterval(ConfidenceInterval):
     """Parametric bootstrap of a process tomography around `channel` (default: the reconstructed
     channel): resampled counts for every input state, batched Choi reconstruction."""

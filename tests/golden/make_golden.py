@@ -659,9 +659,57 @@ def gen_mhmc():
     save("mhmc", **out)
 
 
+# --------------------------------------------------------------------------------------
+# (f) SugiyamaInterval (interval.py:219-265) and HolderInterval (interval.py:421-539)
+# --------------------------------------------------------------------------------------
+def gen_holder():
+    out = {}
+    cls = np.array([0.3, 0.6, 0.9])
+    k = 0
+    for n, povm, shots, seed, dst in ((1, "proj-set", 1000, 1, "hs"), (2, "proj-set", 10000, 2, "trace"),
+                                      (2, "sic", 5000, 3, "if"), (3, "proj-set", 100000, 4, "hs")):
+        rho = ginibre_state(np.random.default_rng(900 + k), 2**n)
+        np.random.seed(seed)
+        t = qp.StateTomograph(qp.Qobj(rho), dst)
+        t.experiment(shots, povm)
+        key = f"S{k}"
+        out[key + "_n"] = np.array(n)
+        out[key + "_povm"] = np.array(povm)
+        out[key + "_dst"] = np.array(dst)
+        out[key + "_counts"] = t.results
+        out[key + "_radii"] = qp.SugiyamaInterval(t, n_points=400)(cls)[0]
+        k += 1
+    out["n_state_cases"] = np.array(k)
+    out["conf_levels"] = cls
+    # Holder: 1-qubit process, three kinds
+    np.random.seed(21)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 1))
+    tmg.experiment(2000, "proj-set")
+    tmg.point_estimate("states")  # gives every inner tomograph its reconstructed_state
+    out["H_counts"] = tmg.results
+    out["H_states"] = np.stack([t_.reconstructed_state.matrix for t_ in tmg.tomographs])
+    r = qp.HolderInterval(tmg, n_points=300, kind="sugiyama")(cls)
+    out["H_sugiyama_dist"], out["H_sugiyama_cl"] = r
+    np.random.seed(31)
+    r = qp.HolderInterval(tmg, n_points=40, kind="bootstrap", method="lin")(cls)
+    out["H_bootstrap_dist"], out["H_bootstrap_cl"] = r
+    np.random.seed(41)
+    r = qp.HolderInterval(tmg, n_points=60, kind="mhmc", step=0.01, burn_steps=20)(cls)
+    out["H_mhmc_dist"], out["H_mhmc_cl"] = r
+    for bad in ("wang", "moment"):
+        try:
+            qp.HolderInterval(tmg, kind=bad)(cls)
+            out["H_error_" + bad] = np.array("none")
+        except Exception as e:  # noqa: BLE001
+            out["H_error_" + bad] = np.array(type(e).__name__)
+    print("   holder:", out["H_sugiyama_dist"], out["H_bootstrap_dist"], out["H_mhmc_dist"], out["H_error_wang"],
+          out["H_error_moment"])
+    save("holder", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large",
-                             "pgdb", "constr", "mhmc"]
+                             "pgdb", "constr", "mhmc", "holder"]
     table = {
         "operators": gen_operators,
         "states": gen_states_and_born,
@@ -675,6 +723,7 @@ if __name__ == "__main__":
         "pgdb": gen_pgdb,
         "constr": gen_constr,
         "mhmc": gen_mhmc,
+        "holder": gen_holder,
     }
     for w in which:
         print(f"[{w}]")

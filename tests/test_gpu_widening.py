@@ -183,3 +183,42 @@ def test_mhmc_state_interval_matches_reference(qp, oracle):
         ptm = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 1))
         ptm.experiment(100, "proj-set")
         qp.MHMCStateInterval(ptm).setup()
+
+
+def test_sugiyama_and_holder_intervals(qp):
+    """SugiyamaInterval (interval.py:219-265) and HolderInterval (interval.py:421-539) against the
+    reference's numbers; the unprovided (cvxopt) intervals exist under the reference's names and say so."""
+    g = load_golden("holder")
+    cls = g["conf_levels"]
+    for k in range(int(g["n_state_cases"])):
+        key = f"S{k}"
+        n = int(g[key + "_n"])
+        tmg = qp.StateTomograph(qp.Qobj(np.eye(2**n) / 2**n), str(g[key + "_dst"]))
+        tmg.experiment(10, str(g[key + "_povm"]))
+        tmg.results = g[key + "_counts"]
+        radii = qp.SugiyamaInterval(tmg, n_points=400)(cls)[0]
+        assert np.abs(radii - g[key + "_radii"]).max() < 1e-10, key
+    np.random.seed(21)
+    ptm = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 1))
+    ptm.experiment(2000, "proj-set")
+    assert np.array_equal(ptm.results, g["H_counts"])
+    ptm.point_estimate("states")
+    for t, want in zip(ptm.tomographs, g["H_states"]):
+        assert np.abs(t.reconstructed_state.matrix - want).max() < 1e-10
+    dist, cl = qp.HolderInterval(ptm, n_points=300, kind="sugiyama")(cls)
+    assert np.abs(dist - g["H_sugiyama_dist"]).max() < 1e-10 and np.abs(cl - g["H_sugiyama_cl"]).max() < 1e-15
+    np.random.seed(31)
+    dist, cl = qp.HolderInterval(ptm, n_points=40, kind="bootstrap", method="lin")(cls)
+    assert np.abs(dist - g["H_bootstrap_dist"]).max() < 1e-10
+    np.random.seed(41)
+    dist, cl = qp.HolderInterval(ptm, n_points=60, kind="mhmc", step=0.01, burn_steps=20)(cls)
+    assert np.abs(dist - g["H_mhmc_dist"]).max() < 1e-9
+    with pytest.raises(ValueError):
+        qp.HolderInterval(ptm)(cls)  # the reference's default kind='wang' has no branch either
+    with pytest.raises(TypeError):
+        qp.HolderInterval(ptm, kind="moment")(cls)
+    assert str(g["H_error_wang"]) == "ValueError" and str(g["H_error_moment"]) == "TypeError"
+    for name in ("MomentFidelityStateInterval", "MomentFidelityProcessInterval", "PolytopeStateInterval",
+                 "PolytopeProcessInterval", "MHMCProcessInterval"):
+        with pytest.raises(NotImplementedError):
+            getattr(qp, name)(ptm)

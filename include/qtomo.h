@@ -156,6 +156,12 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
  * decrease falls below tol.  iters[B], status[B] nullable. */
 int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, double tol, int stop_rule, double* choi,
                   int32_t* iters, int32_t* status, int flags);
+/* Metropolis-Hastings chains on the Choi vector (MHMCProcessInterval, interval.py:808-836): proposals
+ * P_CPTP(x + step * delta), target exp(-nll) with the raw counts.  counts[C][D][S][K], choi_init[C][D][D][2],
+ * deltas[C][T][D*D] (real, indexed like the column-stacked Choi vector), uniforms[C][T];
+ * chain[C][T][D][D][2] = Choi matrix after every step, accepted[C][T]. */
+int qt_mhmc_process(qt_handle_t* h, const int64_t* counts, int C, const double* choi_init, const double* deltas,
+                    const double* uniforms, int T, double step, double* chain, int32_t* accepted, int flags);
 /* projections alone (process.py:231-278): mode 0 = CPTP (Dykstra), 1 = TP, 2 = CP */
 int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode, int n_iter, double tol,
                           double* choi_out, int32_t* iters, int flags);

@@ -874,3 +874,40 @@ def mhmc_state_interval(counts, povm_matrix, state_matrix, n_points, step, burn_
     samples = chain[burn_steps::thinning][:n_points]
     dist = np.sort([hs_dst(tril_vec_to_matrix(v), state_matrix) for v in samples])
     return dist, samples, float(acc[burn_steps:].mean())
+
+
+def mhmc_process_interval(counts, povm_matrix, in_states, channel_choi, n_points, step, burn_steps, thinning=1):
+    """MHMCProcessInterval.setup (interval.py:808-836): chain on the Choi vector with the CPTP projection as
+    update rule (process.py:279-281) and target -nll with the raw counts (process.py:310-314); draws in the
+    reference's order.  Returns (sorted HS distances, sample matrices, acceptance rate)."""
+    from scipy.stats import multivariate_normal
+
+    counts = np.asarray(counts)
+    n = int(round(math.log2(in_states[0].shape[0])))
+    oper = lifp_operator(in_states, povm_matrix, counts[0].sum(-1))
+    unnorm = np.hstack([c.flatten() for c in counts]).astype(float)
+
+    def logp(v):
+        return np.sum(unnorm * np.log(oper @ v + 1e-12))  # = -nll, complex like the reference's
+
+    dim = oper.shape[1]
+    jump = multivariate_normal(mean=np.zeros(dim))
+    db = jump.rvs(size=burn_steps).reshape(burn_steps, dim)
+    ub = np.random.rand(burn_steps)
+    total = n_points * thinning
+    ds = jump.rvs(size=total).reshape(total, dim)
+    us = np.random.rand(total)
+    x = mat2vec(np.asarray(channel_choi, dtype=np.complex128))
+    states, acc = [], []
+    for dl, u in zip(np.concatenate([db, ds]), np.concatenate([ub, us])):
+        xp = mat2vec(cptp_projection(vec2mat(x + step * dl), n))
+        alpha = np.exp(logp(xp) - logp(x))
+        ok = (u, 0.0) <= (alpha.real, alpha.imag)  # NumPy orders complex numbers lexicographically
+        if ok:
+            x = xp
+        states.append(x)
+        acc.append(ok)
+    # mhmc.py:66 stores the samples in a real array: imaginary parts are dropped
+    samples = [vec2mat(v.real) for v in states[burn_steps::thinning][:n_points]]
+    dist = np.sort([hs_dst(m, channel_choi) for m in samples])
+    return dist, samples, float(np.mean(acc[burn_steps:]))

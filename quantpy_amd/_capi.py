@@ -51,6 +51,7 @@ SIGNATURES = {
     "qt_process_get_operators": (_c_int, [_vp, _vp, _vp, _c_int]),
     "qt_lifp_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _c_int]),
     "qt_pgdb_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_dbl, _c_int, _vp, _vp, _vp, _c_int]),
+    "qt_mhmc_process": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _c_int]),
     "qt_cptp_project_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, _vp, _c_int]),
 }
 

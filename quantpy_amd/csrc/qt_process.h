@@ -473,6 +473,80 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT) k_pgdb_batch(const int64_t* __
   }
 }
 
+// Metropolis-Hastings chain on the Choi vector (MHMCProcessInterval, interval.py:808-836; mhmc.py:80-119
+// with update_rule = `_cptp_update_rule`, process.py:279-281): step t proposes
+//   x' = P_CPTP(x + step * delta_t)      (delta real, added entry by entry to the column-stacked vector)
+// and accepts iff u_t <= exp(nll(x) - nll(x')), nll = -sum n log(A x + 1e-12) (process.py:310-314; the
+// complex logarithm enters through its real part, as NumPy orders complex numbers by it).
+// One workgroup per chain; chain_out[c][t] = Choi matrix (row-major) after step t.
+template <int DC>
+__global__ void __launch_bounds__(ProcWG<DC>::NT) k_mhmc_process(const int64_t* __restrict__ counts, int C, int M,
+                                                                const double* __restrict__ lifp,
+                                                                const double* __restrict__ choi_init,
+                                                                const double* __restrict__ deltas,
+                                                                const double* __restrict__ uniforms, int T_steps,
+                                                                double step, double* __restrict__ chain_out,
+                                                                int32_t* __restrict__ accepted) {
+  using W = ProcWG<DC>;
+  constexpr int NE = W::NE, NT = W::NT, NW = NT / 64;
+  __shared__ typename W::Sh sh;
+  __shared__ double cre[NE], cim[NE];
+  extern __shared__ double dynsh[];  // cnt[R] | p[R]
+  const int R = DC * M;
+  double* cnt = dynsh;
+  double* pr = cnt + R;
+  const int b = blockIdx.x;
+  if (b >= C) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool act = tid < NE;
+  const int i = tid / DC, j = tid % DC;
+  const int v_own = j * DC + i;
+  for (int r = tid; r < R; r += NT) cnt[r] = (double)counts[(size_t)b * R + r];
+  double xr = 0.0, xi = 0.0;
+  if (act) {
+    xr = choi_init[((size_t)b * NE + tid) * 2];
+    xi = choi_init[((size_t)b * NE + tid) * 2 + 1];
+  }
+  auto nll_of = [&](double er, double ei) {  // nll of the matrix whose element (i, j) this thread passes in
+    __syncthreads();
+    if (act) {
+      cre[v_own] = er;
+      cim[v_own] = ei;
+    }
+    __syncthreads();
+    for (int r = wave; r < R; r += NW) {
+      const double* a = lifp + (size_t)r * NE * 2;
+      double acc = 0.0;
+      for (int v = lane; v < NE; v += 64) acc += a[2 * v] * cre[v] - a[2 * v + 1] * cim[v];
+      for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+      if (lane == 0) pr[r] = acc;
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int r = tid; r < R; r += NT) part += cnt[r] * log(fabs(pr[r] + 1e-12));
+    return -block_sum<NT>(part, sh.red);
+  };
+  double f = nll_of(xr, xi);
+  for (int t = 0; t < T_steps; ++t) {
+    double pr_ = xr, pi_ = xi;
+    if (act) pr_ += step * deltas[((size_t)b * T_steps + t) * NE + v_own];
+    W::dykstra(sh, act, i, j, pr_, pi_, 1000, 1e-12);
+    const double fn = nll_of(pr_, pi_);
+    const bool acc = uniforms[(size_t)b * T_steps + t] <= exp(f - fn);
+    if (acc) {
+      xr = pr_;
+      xi = pi_;
+      f = fn;
+    }
+    if (act) {
+      double* out = chain_out + (((size_t)b * T_steps + t) * NE + tid) * 2;
+      out[0] = xr;
+      out[1] = xi;
+    }
+    if (tid == 0) accepted[(size_t)b * T_steps + t] = acc ? 1 : 0;
+  }
+}
+
 // mode 0: Dykstra CPTP, 1: TP only, 2: CP only  (process.py:231-278)
 template <int DC>
 __global__ void __launch_bounds__(ProcWG<DC>::NT) k_cptp_project(const double* __restrict__ in, int B, int mode,

@@ -949,6 +949,38 @@ int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, doub
   return count_bad(status, B, flags);
 }
 
+int qt_mhmc_process(qt_handle_t* h, const int64_t* counts, int C, const double* choi_init, const double* deltas,
+                    const double* uniforms, int T, double step, double* chain, int32_t* accepted, int flags) {
+  if (int r = check_handle(h)) return r;
+  if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
+  if (C < 0 || T < 0 || (C > 0 && T > 0 && (!counts || !choi_init || !deltas || !uniforms || !chain || !accepted)))
+    return fail(QT_ERR_ARG, "bad mhmc_process arguments");
+  if (C == 0 || T == 0) return 0;
+  const int D = h->D, M = h->M;
+  const size_t ne = (size_t)D * D;
+  const int64_t* dc;
+  const double *dx, *dd, *du;
+  double* dch;
+  int32_t* dacc;
+  if (int r = stage_in(h, h->in0, counts, (size_t)C * D * M, flags, &dc)) return r;
+  if (int r = stage_in(h, h->in1, choi_init, (size_t)C * ne * 2, flags, &dx)) return r;
+  if (int r = stage_in(h, h->out2, deltas, (size_t)C * T * ne, flags, &dd)) return r;
+  if (int r = stage_in(h, h->out3, uniforms, (size_t)C * T, flags, &du)) return r;
+  if (int r = stage_out(h, h->out0, chain, (size_t)C * T * ne * 2, flags, &dch)) return r;
+  if (int r = stage_out(h, h->out1, accepted, (size_t)C * T, flags, &dacc)) return r;
+  const size_t dyn = (size_t)2 * D * M * sizeof(double);
+  if (dyn > 32 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the process kernel");
+  if (D == 4)
+    hipLaunchKernelGGL(qt::k_mhmc_process<4>, dim3(C), dim3(qt::ProcWG<4>::NT), dyn, h->stream, dc, C, M,
+                       (const double*)h->proc.lifp, dx, dd, du, T, step, dch, dacc);
+  else
+    hipLaunchKernelGGL(qt::k_mhmc_process<16>, dim3(C), dim3(qt::ProcWG<16>::NT), dyn, h->stream, dc, C, M,
+                       (const double*)h->proc.lifp, dx, dd, du, T, step, dch, dacc);
+  if (int r = fetch_out(h, dch, chain, (size_t)C * T * ne * 2, flags)) return r;
+  if (int r = fetch_out(h, dacc, accepted, (size_t)C * T, flags)) return r;
+  return finish(h, flags);
+}
+
 int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode, int n_iter, double tol, double* choi_out,
                           int32_t* iters, int flags) {
   if (int r = check_handle(h)) return r;

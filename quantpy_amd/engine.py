@@ -213,6 +213,20 @@ class Engine:
             choi, iters = choi[0], iters[0]
         return (choi, iters) if return_iters else choi
 
+    def mhmc_process(self, counts, choi_init, deltas, uniforms, step):
+        """Metropolis-Hastings chain of MHMCProcessInterval: counts (D, S, K), choi_init (D, D), deltas
+        (T, D*D) real (column-stacked index), uniforms (T,) -> (chain (T, D, D) complex, accepted (T,))."""
+        c = _i64(counts).reshape(1, self.D, self.S, self.K)
+        x0 = _c128(choi_init).reshape(1, self.D, self.D)
+        dl = _f64(deltas).reshape(1, -1, self.D * self.D)
+        t = dl.shape[1]
+        un = _f64(uniforms).reshape(1, t)
+        chain = np.empty((1, t, self.D, self.D), dtype=np.complex128)
+        acc = np.zeros((1, t), dtype=np.int32)
+        self._chk(self.lib.qt_mhmc_process(self._h, _ptr(c), 1, _ptr(x0), _ptr(dl), _ptr(un), t, float(step), _ptr(chain),
+                                           _ptr(acc), _capi.QT_HOST_PTR))
+        return chain[0], acc[0]
+
     def lifp_dev(self, counts, choi, cptp=True, iters=None, status=None):
         self._chk(self.lib.qt_lifp_batch(self._h, _ptr(counts), counts.shape[0], int(bool(cptp)), _ptr(choi), _ptr(iters),
                                          _ptr(status), _capi.QT_DEVICE_PTR))

@@ -324,14 +324,60 @@ PolytopeProcessInterval = _needs_cvxopt("PolytopeProcessInterval", "338-418")
 
 
 class MHMCProcessInterval(ConfidenceInterval):
-    """Not provided: the reference's chain (interval.py:763-850) projects every proposal onto the CPTP set
-    with a full Dykstra iteration (`_cptp_update_rule`, process.py:279-281)."""
+    """Metropolis-Hastings samples of the process likelihood on the Choi vector (reference
+    interval.py:763-850): every proposal x + step * delta is projected onto the CPTP set
+    (`_cptp_update_rule`, process.py:279-281), the target is exp(-nll) with the raw counts.  Draws on the
+    host in the reference's order, the chain in one launch of `qt_mhmc_process`.  As in the reference,
+    `return_samples=True` makes `setup()` return (dist, conf_levels, acceptance_rate, matrices) instead of
+    preparing the functor."""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("MHMCProcessInterval is not provided (one Dykstra CPTP projection per chain step)")
+    def __init__(self, tmg, n_points=1000, step=0.01, burn_steps=1000, thinning=1, warm_start=False, method="lifp",
+                 states_est_method="lin", states_physical=True, states_init="lin", use_new_estimate=False,
+                 channel=None, verbose=False, return_samples=False):
+        super().__init__(tmg, **_pop_hidden_keys(locals()))
 
     def setup(self):
-        pass
+        from scipy.stats import multivariate_normal
+
+        if self.mode == Mode.STATE:
+            raise NotImplementedError("This interval works only for process tomography")
+        tmg = self.tmg
+        if not self.use_new_estimate:
+            self.channel = tmg.reconstructed_channel
+        elif self.channel is None:
+            self.channel = tmg.point_estimate(self.method, states_est_method=self.states_est_method,
+                                              states_physical=self.states_physical, states_init=self.states_init)
+        eng = tmg._engine()
+        dim = 16**tmg.channel.n_qubits
+        centre = np.asarray(self.channel.choi.matrix, dtype=np.complex128)
+        if not (self.warm_start and hasattr(self, "_x_t")):
+            self._x_t, self._burned = centre.copy(), False
+        jump = multivariate_normal(mean=np.zeros(dim))
+        parts = []
+        if not self._burned:
+            parts.append((jump.rvs(size=self.burn_steps).reshape(self.burn_steps, dim), np.random.rand(self.burn_steps)))
+        total = self.n_points * self.thinning
+        parts.append((jump.rvs(size=total).reshape(total, dim), np.random.rand(total)))
+        deltas = np.concatenate([p[0] for p in parts])
+        uniforms = np.concatenate([p[1] for p in parts])
+        chain, accepted = eng.mhmc_process(tmg.results, self._x_t, deltas, uniforms, self.step)
+        skip = 0 if self._burned else self.burn_steps
+        self._burned = True
+        if len(chain):
+            self._x_t = chain[-1].copy()
+        # mhmc.py:66 collects the samples in a REAL array: the imaginary parts of the chain states are
+        # dropped there (NumPy's ComplexWarning), and the distances are those of the real parts
+        self.samples = np.ascontiguousarray(chain[skip::self.thinning][: self.n_points].real)
+        self.acceptance_rate = float(accepted[skip:].mean()) if total else 0.0
+        if tmg.dst is hs_dst:
+            dist = get_engine(self.channel.choi.n_qubits).hs_dist(self.samples, centre)
+        else:
+            dist = np.array([tmg.dst(m, centre) for m in self.samples], dtype=np.float64)
+        dist = np.sort(dist)
+        conf_levels = np.linspace(0, 1, len(dist))
+        if self.return_samples:
+            return dist, conf_levels, self.acceptance_rate, list(self.samples)
+        self.cl_to_dist = interp1d(conf_levels, dist)
 
 
 class BootstrapProcessInterval(ConfidenceInterval):

@@ -656,6 +656,27 @@ def gen_mhmc():
         k += 1
     out["n_cases"] = np.array(k)
     out["conf_levels"] = cls
+    # process chains (interval.py:763-850): every proposal goes through the Dykstra projection
+    for key, n, mk, shots, seed, n_points, burn, step in (("Q0", 1, lambda: qp.channel.depolarizing(0.1, 1), 2000, 51, 40, 15, 0.01),
+                                                          ("Q1", 2, lambda: qp.channel.depolarizing(0.2, 2), 5000, 52, 12, 5, 0.003)):
+        np.random.seed(seed)
+        tmg = qp.ProcessTomograph(mk())
+        tmg.experiment(shots, "proj-set")
+        ch = tmg.point_estimate("lifp")
+        np.random.seed(200 + seed)
+        iv = qp.MHMCProcessInterval(tmg, n_points=n_points, step=step, burn_steps=burn, return_samples=True)
+        dist, cl, rate, mats = iv.setup()
+        out[key + "_n"] = np.array(n)
+        out[key + "_seed"] = np.array(seed)
+        out[key + "_shots"] = np.array(shots)
+        out[key + "_counts"] = tmg.results
+        out[key + "_channel"] = ch.choi.matrix
+        out[key + "_args"] = np.array([n_points, burn])
+        out[key + "_step"] = np.array(step)
+        out[key + "_dist"] = dist
+        out[key + "_rate"] = np.array(rate)
+        out[key + "_samples"] = np.stack(mats)
+        print(f"   {key}: n={n} acceptance {rate:.3f} dist {dist[:3]} ...")
     save("mhmc", **out)
 
 

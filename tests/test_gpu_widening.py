@@ -219,6 +219,30 @@ def test_sugiyama_and_holder_intervals(qp):
         qp.HolderInterval(ptm, kind="moment")(cls)
     assert str(g["H_error_wang"]) == "ValueError" and str(g["H_error_moment"]) == "TypeError"
     for name in ("MomentFidelityStateInterval", "MomentFidelityProcessInterval", "PolytopeStateInterval",
-                 "PolytopeProcessInterval", "MHMCProcessInterval"):
+                 "PolytopeProcessInterval"):
         with pytest.raises(NotImplementedError):
             getattr(qp, name)(ptm)
+
+
+def test_mhmc_process_interval_matches_reference(qp):
+    """MHMCProcessInterval through qt_mhmc_process against the reference's samples (golden, same seeds)."""
+    g = load_golden("mhmc")
+    makers = {"Q0": lambda: qp.channel.depolarizing(0.1, 1), "Q1": lambda: qp.channel.depolarizing(0.2, 2)}
+    for key, mk in makers.items():
+        np.random.seed(int(g[key + "_seed"]))
+        tmg = qp.ProcessTomograph(mk())
+        tmg.experiment(int(g[key + "_shots"]), "proj-set")
+        assert np.array_equal(tmg.results, g[key + "_counts"])
+        ch = tmg.point_estimate("lifp")
+        assert np.abs(ch.choi.matrix - g[key + "_channel"]).max() < 1e-9
+        n_points, burn = (int(v) for v in g[key + "_args"])
+        np.random.seed(200 + int(g[key + "_seed"]))
+        iv = qp.MHMCProcessInterval(tmg, n_points=n_points, step=float(g[key + "_step"]), burn_steps=burn,
+                                    return_samples=True)
+        dist, cl, rate, mats = iv.setup()
+        assert np.abs(np.stack(mats) - g[key + "_samples"]).max() < 1e-8, key
+        assert np.abs(dist - g[key + "_dist"]).max() < 1e-8, key
+        assert abs(rate - float(g[key + "_rate"])) < 1e-12, key
+        np.random.seed(200 + int(g[key + "_seed"]))
+        radii = qp.MHMCProcessInterval(tmg, n_points=n_points, step=float(g[key + "_step"]), burn_steps=burn)([0.5])[0]
+        assert np.abs(radii - np.interp(0.5, np.linspace(0, 1, n_points), g[key + "_dist"])).max() < 1e-8

@@ -271,3 +271,19 @@ def test_mhmc_state_interval_against_reference(oracle):
         q = np.interp(g["conf_levels"], np.linspace(0, 1, len(dist)), dist)
         assert np.abs(q - g[key + "_radii"]).max() < 1e-12, key
         assert 0.0 < rate <= 1.0
+
+
+def test_mhmc_process_interval_against_reference(oracle):
+    """MHMCProcessInterval (interval.py:763-850): the oracle's chain reproduces the reference's samples."""
+    g = load_golden("mhmc")
+    for key in ("Q0", "Q1"):
+        n = int(g[key + "_n"])
+        povm = oracle.measurement_matrix("proj-set", n)
+        ins = oracle.input_states("proj4", n)
+        n_points, burn = (int(v) for v in g[key + "_args"])
+        np.random.seed(200 + int(g[key + "_seed"]))
+        dist, samples, rate = oracle.mhmc_process_interval(g[key + "_counts"], povm, ins, g[key + "_channel"], n_points,
+                                                          float(g[key + "_step"]), burn)
+        assert np.abs(np.stack(samples) - g[key + "_samples"]).max() < 1e-10, key
+        assert np.abs(dist - g[key + "_dist"]).max() < 1e-10, key
+        assert abs(rate - float(g[key + "_rate"])) < 1e-12, key

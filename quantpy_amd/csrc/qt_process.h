@@ -77,10 +77,14 @@ struct ProcWG {
   static constexpr int NT = NE < 64 ? 64 : NE;     // workgroup size
   static constexpr int DQ = (DC == 4) ? 2 : (DC == 16 ? 4 : 8);  // d = sqrt(DC)
 
+  // Row pitch DC + 1 for the DC x DC images: with pitch DC (128 bytes at DC = 16) the column-wise
+  // reads of the Jacobi rounds and of the rebuild fall on two banks (8-way conflicts).
+  static constexpr int LDC = DC + 1;
+  static constexpr int NEP = DC * LDC;
   struct Sh {
-    double are[NE], aim[NE];   // work matrix
-    double tre[NE], tim[NE];   // column-rotated matrix
-    double vre[2][NE], vim[2][NE];  // eigenvectors, double buffered
+    double are[NEP], aim[NEP];   // work matrix
+    double tre[NEP], tim[NEP];   // column-rotated matrix
+    double vre[2][NEP], vim[2][NEP];  // eigenvectors, double buffered
     double rc[DC], ore[DC], oim[DC];
     double red[16];
     double rre[DQ * DQ], rim[DQ * DQ];  // reduced (input-space) matrix of the TP step
@@ -97,7 +101,7 @@ struct ProcWG {
   // CP projection (process.py:270-277): eigh on the lower triangle, clip at eps, rebuild.
   // (re, im) = this thread's element (i, j); returns the projected element.
   __device__ static void cp_project(Sh& sh, bool act, int i, int j, double& re, double& im, double eps) {
-    const int e = i * DC + j;
+    const int e = i * LDC + j;
     // Hermitian completion from the lower triangle, like LAPACK's zheevd with uplo = 'L'
     if (act) {
       sh.are[e] = re;
@@ -112,8 +116,8 @@ struct ProcWG {
       } else if (i == j) {
         ar = re;
       } else {
-        ar = sh.are[j * DC + i];
-        ai = -sh.aim[j * DC + i];
+        ar = sh.are[j * LDC + i];
+        ai = -sh.aim[j * LDC + i];
       }
       vr = (i == j) ? 1.0 : 0.0;
     }
@@ -143,8 +147,8 @@ struct ProcWG {
             pb = (r - t + (DC - 1)) % (DC - 1);
           }
           const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
-          const double app = sh.are[p * DC + p], aqq = sh.are[q * DC + q];
-          const double xr = sh.are[p * DC + q], xi = sh.aim[p * DC + q];
+          const double app = sh.are[p * LDC + p], aqq = sh.are[q * LDC + q];
+          const double xr = sh.are[p * LDC + q], xi = sh.aim[p * LDC + q];
           const double ab2 = xr * xr + xi * xi;
           double cs = 1.0, wre = 0.0, wim = 0.0;  // w = s e^{i phi} = c u a_pq  (see qt_small.h)
           if (ab2 > 1e-300) {
@@ -172,10 +176,10 @@ struct ProcWG {
           ci = sh.rc[i];
           oir = sh.ore[i];
           oii = sh.oim[i];
-          const double br = sh.are[i * DC + pj], bi = sh.aim[i * DC + pj];
+          const double br = sh.are[i * LDC + pj], bi = sh.aim[i * LDC + pj];
           t_r = ar * cj + (br * ojr - bi * oji);
           t_i = ai * cj + (br * oji + bi * ojr);
-          const double wr = sh.vre[cur][i * DC + pj], wi = sh.vim[cur][i * DC + pj];
+          const double wr = sh.vre[cur][i * LDC + pj], wi = sh.vim[cur][i * LDC + pj];
           const double nvr = vr * cj + (wr * ojr - wi * oji);
           const double nvi = vi * cj + (wr * oji + wi * ojr);
           vr = nvr;
@@ -188,7 +192,7 @@ struct ProcWG {
         cur ^= 1;
         __syncthreads();
         if (act) {
-          const double ur = sh.tre[pi * DC + j], ui = sh.tim[pi * DC + j];
+          const double ur = sh.tre[pi * LDC + j], ui = sh.tim[pi * LDC + j];
           ar = ci * t_r + (oir * ur + oii * ui);  // ci T_ij + conj(o_i) T[pi][j]
           ai = ci * t_i + (oir * ui - oii * ur);
           if (j == pi) {
@@ -205,10 +209,10 @@ struct ProcWG {
     if (act) {
       double rr = 0.0, ri = 0.0;
       for (int k = 0; k < DC; ++k) {
-        const double lam = sh.are[k * DC + k];
+        const double lam = sh.are[k * LDC + k];
         const double lc = lam > eps ? lam : eps;
-        const double xr = sh.vre[cur][i * DC + k], xi = sh.vim[cur][i * DC + k];
-        const double yr = sh.vre[cur][j * DC + k], yi = sh.vim[cur][j * DC + k];
+        const double xr = sh.vre[cur][i * LDC + k], xi = sh.vim[cur][i * LDC + k];
+        const double yr = sh.vre[cur][j * LDC + k], yi = sh.vim[cur][j * LDC + k];
         rr += lc * (xr * yr + xi * yi);  // V_ik conj(V_jk)
         ri += lc * (xi * yr - xr * yi);
       }
@@ -221,7 +225,7 @@ struct ProcWG {
   // TP projection (process.py:259-265) of the matrix whose element (i, j) this thread holds:
   // C[(a,o),(b,o)] += (delta_ab - sum_o' C[(a,o'),(b,o')]) / d ; other entries unchanged.
   __device__ static void tp_project(Sh& sh, bool act, int i, int j, double& re, double& im) {
-    const int e = i * DC + j;
+    const int e = i * LDC + j;
     if (act) {
       sh.tre[e] = re;
       sh.tim[e] = im;
@@ -231,8 +235,8 @@ struct ProcWG {
       const int a = threadIdx.x / DQ, b = threadIdx.x % DQ;
       double sr = 0.0, si = 0.0;
       for (int o = 0; o < DQ; ++o) {
-        sr += sh.tre[(a * DQ + o) * DC + (b * DQ + o)];
-        si += sh.tim[(a * DQ + o) * DC + (b * DQ + o)];
+        sr += sh.tre[(a * DQ + o) * LDC + (b * DQ + o)];
+        si += sh.tim[(a * DQ + o) * LDC + (b * DQ + o)];
       }
       sh.rre[threadIdx.x] = sr;
       sh.rim[threadIdx.x] = si;
@@ -326,14 +330,14 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT) k_lifp_batch(const int64_t* __
   // thread col*DC+row, i.e. the transposed position
   __syncthreads();
   if (act) {
-    sh.tre[row * DC + col] = xr;
-    sh.tim[row * DC + col] = xi;
+    sh.tre[row * W::LDC + col] = xr;
+    sh.tim[row * W::LDC + col] = xi;
   }
   __syncthreads();
   const int i = tid / DC, j = tid % DC;
   if (act) {
-    xr = sh.tre[tid];
-    xi = sh.tim[tid];
+    xr = sh.tre[i * W::LDC + j];
+    xi = sh.tim[i * W::LDC + j];
   }
   __syncthreads();
   int it = 0;

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--bootstrap-points", type=int, default=2000)
     ap.add_argument("--saturation-batch", type=int, default=65536, help="extra (untimed-contract) measurement; 0 = off")
     ap.add_argument("--pipelined-steps", type=int, default=1000, help="extra: steps alternated over two streams; 0 = off")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / configs[4] side measurements")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     args = ap.parse_args()
@@ -210,6 +211,53 @@ def main():
                  "outputs_identical_across_streams": same}
         eng2.close()
 
+    # ---- the other single-GPU configurations of BASELINE.json, one short measurement each ---------
+    others = None
+    if rank == 0 and not args.no_other_configs:
+        others = {}
+        # configs[2]: 2-qubit process tomography of a depolarizing channel, Choi linear inversion + CPTP
+        np.random.seed(11)
+        ptm = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 2))
+        ptm.experiment(10000, "proj-set")
+        peng = ptm._engine()
+        pb = 1024
+        pc = torch.from_numpy(np.ascontiguousarray(np.stack([ptm.results] * pb))).cuda()
+        pout = torch.empty((pb, 16, 16), dtype=torch.complex128, device="cuda")
+        for cptp in (False, True):
+            peng.lifp_dev(pc, pout, cptp=cptp)
+            peng.sync()
+            peng.timer_begin()
+            for _ in range(5):
+                peng.lifp_dev(pc, pout, cptp=cptp)
+            ms = peng.timer_end() / 5
+            others["configs[2] lifp" + (" + CPTP projection" if cptp else "")] = {
+                "batch": pb, "ms_per_launch": round(ms, 4), "value": round(pb / ms * 1e3, 1), "unit": "Choi reconstructions/s"}
+        del pc, pout
+        # configs[4]: 5-qubit MLE, tensor-product Pauli POVM, 1e6 shots per setting (per-GPU figure)
+        n5 = 5
+        rho5 = ginibre(np.random.default_rng(1234), 2**n5)
+        povm5 = qp.generate_measurement_matrix("proj-set", n5)
+        shots5 = np.ones(povm5.shape[0]) * 10**6
+        np.random.seed(7)
+        few = np.stack([simulate_counts(povm5, qp.Qobj(rho5).bloch, shots5) for _ in range(8)])
+        b5 = 256
+        e5 = qp.get_engine(n5, device=dev_index)
+        e5.set_povm(povm5, shots5)
+        c5 = torch.from_numpy(np.ascontiguousarray(np.concatenate([few] * (b5 // 8)))).cuda()
+        r5 = torch.empty((b5, 32, 32), dtype=torch.complex128, device="cuda")
+        st5 = torch.zeros(b5, dtype=torch.int32, device="cuda")
+        for name, fn in (("lin", lambda: e5.lin_dev(c5, r5)), ("mle", lambda: e5.mle_dev(c5, r5, status=st5))):
+            fn()
+            e5.sync()
+            e5.timer_begin()
+            for _ in range(5):
+                fn()
+            ms = e5.timer_end() / 5
+            others[f"configs[4] 5-qubit {name}"] = {"batch": b5, "ms_per_launch": round(ms, 4),
+                                                   "value": round(b5 / ms * 1e3, 1), "unit": "reconstructions/s"}
+        assert int(st5.sum().item()) == 0
+        del c5, r5
+
     # ---- bootstrap CI (configs[3]): strong scaling over ranks, one all-gather -------------------
     boot = None
     if args.bootstrap_points > 0:
@@ -292,6 +340,7 @@ def main():
             "cpu_baseline": cpu,
             "saturated_batch": sat,
             "two_stream_pipeline": piped,
+            "other_configs": others,
             "bootstrap_ci": boot,
         }
         print(json.dumps(line), flush=True)

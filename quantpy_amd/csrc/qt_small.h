@@ -846,7 +846,13 @@ struct Small {
       if (!lifted) proj = psd_project(c, r, 1e-15);  // whole wave runs it; PD trials keep their shortcut
       QT_STAMP(6);
       int ok2 = 1;
-      const double x2 = xl ? cholesky_param(c, proj, ok2) : 0.0;
+      double x2 = xl ? cholesky_param(c, proj, ok2) : 0.0;
+      if (lifted && xl && !__all(ok2 || ok)) {
+        // the short cut left something non-positive behind (an inertia count thrown off by a pivot at
+        // rounding level): take the eigensolver after all
+        proj = psd_project(c, r, 1e-15);
+        x2 = cholesky_param(c, proj, ok2);
+      }
       QT_STAMP(7);
       if (!ok) {
         out = proj;

@@ -297,8 +297,8 @@ struct Small {
   static constexpr int oA = 0;             // complex [d][LD]
   static constexpr int oB = oA + MAT;      // complex [d][LD]
   static constexpr int oV = oB + MAT;      // complex [d][LD]
-  static constexpr int oVec = oV + MAT;    // [D]
-  static constexpr int oLam = oVec + D;    // [d] (+ pad to even)
+  static constexpr int oVec = oV + MAT;    // [D] + one slot that always holds 0 (source of L's zero entries)
+  static constexpr int oLam = oVec + D + 2;  // [d] (+ pad to even)
   static constexpr int oM = oLam + 2 * ((d + 1) / 2);  // rbuf[Mp], freq[Mp], bufB[Mp], tables[8 R1]
   __host__ __device__ static int trial_doubles(int M, int R1 = 0) {
     const int Mp = (M + 1) & ~1;
@@ -343,6 +343,8 @@ struct Small {
     int xm, zm, ny;
     // Cholesky parameter owned by lane l: element (pi, pj), kind 0 diag / 1 real / 2 imag
     int pi, pj, pkind;
+    // where element (i, j) of L finds its real / imaginary part in the parameter vector (D = the zero slot)
+    int src_re, src_im;
     __device__ __forceinline__ cd* A() const { return reinterpret_cast<cd*>(sm + oA); }
     __device__ __forceinline__ cd* Bm() const { return reinterpret_cast<cd*>(sm + oB); }
     __device__ __forceinline__ cd* V() const { return reinterpret_cast<cd*>(sm + oV); }
@@ -419,6 +421,14 @@ struct Small {
       c.pi = ii;
       c.pj = t - (ii * (ii - 1)) / 2;
     }
+    c.src_re = c.src_im = D;
+    if (c.i == c.j) c.src_re = c.i;
+    else if (c.i > c.j) {
+      const int tt = (c.i * (c.i - 1)) / 2 + c.j;
+      c.src_re = d + tt;
+      c.src_im = d + T + tt;
+    }
+    if (c.l == 0) c.sm[oVec + D] = 0.0;  // (this trial's scratch: c.sm is set above)
   }
 
   // Cooperative copy of a row-major [M][D] operand into the padded LDS image (whole workgroup).
@@ -873,19 +883,15 @@ struct Small {
     tr = gsum<G>(xl * xl);
     wave_sync();
     const int i = c.i, j = c.j;
-    cd lij{0.0, 0.0};
-    if (i == j) lij.re = vx[i];
-    else if (i > j) {
-      const int t = (i * (i - 1)) / 2 + j;
-      lij = cd{vx[d + t], vx[d + T + t]};
-    }
-    L[c.e] = lij;
+    L[c.e] = cd{vx[c.src_re], vx[c.src_im]};  // branch-free: the zero slot feeds the upper triangle
     wave_sync();
     cd m{0.0, 0.0};
-    const int kmax = i < j ? i : j;
 #pragma unroll
-    for (int k = 0; k < d; ++k)
-      if (k <= kmax) m = cadd(m, cmulc(L[i * LD + k], L[j * LD + k]));
+    for (int k = 0; k < d; ++k) {  // all k: the zeros of L contribute exact zeros
+      const cd u = L[i * LD + k], v = L[j * LD + k];
+      m.re = fma(u.re, v.re, fma(u.im, v.im, m.re));
+      m.im = fma(u.im, v.re, fma(-u.re, v.im, m.im));
+    }
     return m;
   }
 
@@ -969,8 +975,11 @@ struct Small {
     const cd* L = c.Bm();
     cd q{0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < d; ++k)
-      if (k >= c.pj) q = cadd(q, cmul(A[c.pi * LD + k], L[k * LD + c.pj]));
+    for (int k = 0; k < d; ++k) {  // all k: L[k][pj] = 0 above the diagonal
+      const cd u = A[c.pi * LD + k], v = L[k * LD + c.pj];
+      q.re = fma(u.re, v.re, fma(-u.im, v.im, q.re));
+      q.im = fma(u.re, v.im, fma(u.im, v.re, q.im));
+    }
     gl = 2.0 * (c.pkind == 2 ? q.im : q.re);
     wave_sync();
     QT_STAMP(18);

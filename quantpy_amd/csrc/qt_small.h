@@ -474,15 +474,51 @@ struct Small {
   }
 
   // Element (i, j) of sum_k v[k] P_k, v in LDS (qobj.py:114-117).
+  // Element (i, j) of sum_k v[k] P_k needs d of the D terms: k = pauli_index(i ^ j, z), z < d, each
+  // with phase (-i)^popc(x & z) (-1)^popc(i & z).  Which k, real or imaginary, which sign: one byte
+  // per z (k | imaginary << 6 | negative << 7), a pure function of the lane, folded at compile time
+  // into a 64-entry table -- the run-time version spent ~25 integer instructions per term on it.
+  static constexpr uint64_t mat_pack(int l) {
+    const int i = l / d, j = l % d, x = i ^ j;
+    uint64_t pack = 0;
+    for (int z = 0; z < d; ++z) {
+      int k = 0, ny = 0, par = 0;
+      for (int b = 0; b < NQ; ++b) {
+        const int xb = (x >> b) & 1, zb = (z >> b) & 1;
+        const int dig = xb ? (zb ? 2 : 1) : (zb ? 3 : 0);
+        k |= dig << (2 * b);
+        ny += xb & zb;
+        par ^= ((i >> b) & 1) & zb;
+      }
+      ny &= 3;
+      const int imag = ny & 1;                       // (-i)^ny: 1, -i, -1, i
+      const int neg = ((ny == 1 || ny == 2) ? 1 : 0) ^ par;
+      pack |= (uint64_t)(k | (imag << 6) | (neg << 7)) << (8 * z);
+    }
+    return pack;
+  }
+  template <int... L>
+  struct MatTab {
+    static constexpr uint64_t v[sizeof...(L)] = {mat_pack(L)...};
+  };
+  template <int N, int... L>
+  struct MakeMatTab : MakeMatTab<N - 1, N - 1, L...> {};
+  template <int... L>
+  struct MakeMatTab<0, L...> {
+    using type = MatTab<L...>;
+  };
+  static_assert(NQ <= 3, "the packed table holds d <= 8 terms of 8 bits");
   __device__ static cd matrix_of(const Ctx& c, const double* v) {
-    const int x = c.i ^ c.j;
+    using Tab = typename MakeMatTab<D>::type;
+    const uint64_t pack = Tab::v[c.l];
     cd s{0.0, 0.0};
 #pragma unroll
     for (int z = 0; z < d; ++z) {
-      const int k = pauli_index(x, z);
-      const int ny = __popc(x & z) & 3;
-      const double sg = (__popc(c.i & z) & 1) ? -1.0 : 1.0;
-      s = cadd(s, phase_times(ny, sg * v[k]));
+      const uint32_t e = (uint32_t)(pack >> (8 * z)) & 0xffu;
+      double val = v[e & 63u];
+      val = (e & 0x80u) ? -val : val;
+      if (e & 0x40u) s.im += val;
+      else s.re += val;
     }
     return s;
   }

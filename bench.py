@@ -49,7 +49,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2000, help="trials timed on the CPU oracle")
     ap.add_argument("--bootstrap-points", type=int, default=2000)
     ap.add_argument("--saturation-batch", type=int, default=65536, help="extra (untimed-contract) measurement; 0 = off")
-    ap.add_argument("--pipelined-steps", type=int, default=1000, help="extra: steps alternated over two streams; 0 = off")
+    ap.add_argument("--pipelined-steps", type=int, default=0,
+                    help="extra: this many steps alternated over two streams (off by default so that a rocprofv3 pass over the "
+                         "default command sees single-stream launches only)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / configs[4] side measurements")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")

@@ -7,7 +7,7 @@ set -e
 TAG=${1:-prof}
 OUT=$PWD/gpurun_out
 export TMPDIR=/tmp
-ARGS="bench.py --steps 20 --warmup 3 --no-cpu-baseline --bootstrap-points 0 --saturation-batch 0 --pipelined-steps 0 --no-other-configs"
+ARGS="bench.py --steps 20 --warmup 3 --no-cpu-baseline --bootstrap-points 0 --saturation-batch 0 --no-other-configs"
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o run --output-format csv -- python3 bench.py > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o run --output-format csv -- python3 $ARGS > $OUT/${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o run --output-format csv -- python3 $ARGS > $OUT/${TAG}_write.log 2>&1

@@ -84,7 +84,9 @@ struct qt_handle {
   bool proc_set = false;
 
   qt::PovmView view() const { return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod, jtol2}; }
-  double jtol2 = getenv("QT_JACOBI_TOL2") ? atof(getenv("QT_JACOBI_TOL2")) : 1e-28;
+  // Jacobi stopping rule off^2 <= jtol2 * ||A||_F^2.  Measured on the C2 batch: the last sweep takes off^2
+  // from > 1e-9 to < 1e-28 in one go, so no looser threshold saves a sweep without costing accuracy.
+  double jtol2 = 1e-28;
 };
 
 namespace {

@@ -19,9 +19,10 @@ def pytest_collection_modifyitems(config, items):
     library is the only implementation there is, so a missing one must not turn into skips."""
     if not any(item.get_closest_marker("gpu") for item in items):
         return
-    from quantpy_amd.build import build_library
+    from quantpy_amd.build import LIB, build_library
 
-    build_library()
+    if not os.path.exists(LIB):  # (a stale-by-mtime check would misfire on a freshly copied tree)
+        build_library(force=True)
 
 
 def load_golden(name):

@@ -174,20 +174,27 @@ struct Large {
     const double v = c.ny == 0 ? s.re : c.ny == 1 ? s.im : c.ny == 2 ? -s.re : -s.im;
     return v / d;
   }
+  // spread(b): bit q of b moved to bit 2q.  pauli_index(x, z) has digit bits (hi, lo) = (z_q, x_q ^ z_q), i.e.
+  // index = spread(x) ^ 3 * spread(z): one XOR per term with the per-thread spread(x) and the constant 3 * spread(z).
+  __host__ __device__ static constexpr int spread(int b) {
+    int r = 0;
+    for (int q = 0; q < NQ; ++q) r |= ((b >> q) & 1) << (2 * q);
+    return r;
+  }
   __device__ static cd matrix_of(const Ctx& c, const double* v) {
     const int x = c.i ^ c.j;
-    cd s{0.0, 0.0};
+    const int sx = spread(x);
+    double re = 0.0, im = 0.0;
+#pragma unroll 8
     for (int z = 0; z < d; ++z) {
-      const int k = pauli_index(x, z);
-      const double val = ((__popc(c.i & z) & 1) ? -1.0 : 1.0) * v[k];
-      switch (__popc(x & z) & 3) {
-        case 0: s.re += val; break;
-        case 1: s.im -= val; break;
-        case 2: s.re -= val; break;
-        default: s.im += val; break;
-      }
+      const double val = v[sx ^ (3 * spread(z))];
+      const int ny = __popc(x & z);                    // phase (-i)^ny: 1, -i, -1, i
+      const int neg = (ny ^ (ny >> 1) ^ __popc(c.i & z)) & 1;  // -1 for ny = 1, 2; times (-1)^popc(i & z)
+      const double sv = neg ? -val : val;
+      re += (ny & 1) ? 0.0 : sv;
+      im += (ny & 1) ? sv : 0.0;
     }
-    return s;
+    return cd{re, im};
   }
 
   // ---- factorised contractions (qt_small.h for the scheme) -------------------------------------
@@ -205,32 +212,78 @@ struct Large {
                  fma(row[2], in[base + 2 * stride], fma(row[1], in[base + stride], row[0] * in[base])));
     }
     double acc = 0.0;
+    if (R1 == 6) {  // table height known: all 12 reads issued together (a run-time trip count serialises them)
+      double tv[6], iv[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        tv[r] = tb[r * 4 + sel];
+        iv[r] = in[base + r * stride];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc = fma(tv[r], iv[r], acc);
+      return acc;
+    }
+    if (R1 == 4) {
+      double tv[4], iv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        tv[r] = tb[r * 4 + sel];
+        iv[r] = in[base + r * stride];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = fma(tv[r], iv[r], acc);
+      return acc;
+    }
     for (int r = 0; r < R1; ++r) acc = fma(tb[r * 4 + sel], in[base + r * stride], acc);
     return acc;
   }
+  // (base | sel << 16) of output o of a stage whose untouched Pauli indices span 4^(n-q) = 1 << lk entries
+  // (the closed form of the host tables of qt_set_povm_product; at n = 4, 5 those are 135 KB -- too
+  // big for LDS -- and a dependent L2 load per output costs more than these few integer operations):
+  //   forward : o = [r_pre][r_q][k_rest] -> base = r_pre * 4 * Kq + k_rest, sel = r_q
+  //   backward: o = [r_pre][k_q][k_rest] -> base = r_pre * R1 * Kq + k_rest, sel = k_q
   template <bool FWD>
-  __device__ static void stage(const Ctx& c, const double* tb, const int* tab, int n_out, int stride, const double* in,
-                               double* out) {
-    for (int o = c.t; o < n_out; o += NT) out[o] = stage_value<FWD>(tb, c.pr.R1, tab[o], stride, in);
+  __device__ __forceinline__ static int stage_entry(int R1, int lk, int o) {
+    const int krest = o & ((1 << lk) - 1);
+    if (FWD) {
+      const int t = o >> lk;
+      int rpre, rq;
+      if (R1 == 6) {
+        rpre = t / 6;
+        rq = t - 6 * rpre;
+      } else if (R1 == 4) {
+        rpre = t >> 2;
+        rq = t & 3;
+      } else {
+        rpre = t / R1;
+        rq = t - R1 * rpre;
+      }
+      return ((rpre << (lk + 2)) + krest) | (rq << 16);
+    }
+    const int rpre = o >> (lk + 2), kq = (o >> lk) & 3;
+    return ((rpre * R1 << lk) + krest) | (kq << 16);
+  }
+  template <bool FWD>
+  __device__ static void stage(const Ctx& c, const double* tb, int lk, int n_out, const double* in, double* out) {
+    const int R1 = c.pr.R1;
+    for (int o = c.t; o < n_out; o += NT) out[o] = stage_value<FWD>(tb, R1, stage_entry<FWD>(R1, lk, o), 1 << lk, in);
     __syncthreads();
   }
   // Backward pass from Y_n held in X (R-order) to this thread's Y_0[k = t].  Stage n: X -> Y, then
   // alternating; tb = tabT (A^T y) or tabP (A^+ f).
   __device__ static double prod_backward(const Ctx& c, const double* tb) {
     const int R1 = c.pr.R1;
-    const int* tab = c.pr.bwd;
     const double* in = c.X();
     double* bufs[2] = {c.Y(), c.X()};
     int which = 0;
     for (int q = NQ; q >= 2; --q) {
-      const int stride = 1 << (2 * (NQ - q));
-      const int n_out = ipow(R1, q - 1) * 4 * stride;
-      stage<false>(c, tb, tab, n_out, stride, in, bufs[which]);
-      tab += n_out;
+      const int lk = 2 * (NQ - q);
+      const int n_out = ipow(R1, q - 1) * 4 << lk;
+      stage<false>(c, tb, lk, n_out, in, bufs[which]);
       in = bufs[which];
       which ^= 1;
     }
-    const double r = stage_value<false>(tb, R1, tab[c.t], 1 << (2 * (NQ - 1)), in);
+    const double r = stage_value<false>(tb, R1, stage_entry<false>(R1, 2 * (NQ - 1), c.t), 1 << (2 * (NQ - 1)), in);
     __syncthreads();
     return r;
   }
@@ -383,28 +436,30 @@ struct Large {
   // spills them (1.4 KB of scratch per thread, reloaded inside every Cholesky / Jacobi step).
   __device__ __attribute__((noinline)) static void nll_grad(const Ctx& c, double xt, double& f, double& gt) {
     double tr;
+    QT_STAMP(11);
     const cd m = build_llh(c, xt, tr);
+    QT_STAMP(12);
     cd* A = c.Aimg();
     A[c.e] = cd{m.re / tr, m.im / tr};
     __syncthreads();
     const double bl = bloch_of(c, A);
+    QT_STAMP(13);
     double* vec = c.vec();
     vec[c.t] = bl;
     __syncthreads();
     const int R1 = c.pr.R1;
-    const int* tab = c.pr.fwd;
     const double* in = vec;
     for (int q = 1; q < NQ; ++q) {  // stages 1 .. n-1 alternate so that stage n-1 lands in Y
-      const int stride = 1 << (2 * (NQ - q));
-      const int n_out = ipow(R1, q) * stride;
+      const int lk = 2 * (NQ - q);
+      const int n_out = ipow(R1, q) << lk;
       double* out = ((NQ - 1 - q) & 1) ? c.X() : c.Y();
-      stage<true>(c, c.tabT(), tab, n_out, stride, in, out);
-      tab += n_out;
+      stage<true>(c, c.tabT(), lk, n_out, in, out);
       in = out;
     }
+    QT_STAMP(14);
     double fpart = 0.0;
     for (int o = c.t; o < c.M; o += NT) {  // stage n fused with the likelihood terms; Y_n -> X
-      const double xn = stage_value<true>(c.tabT(), R1, tab[o], 1, in);
+      const double xn = stage_value<true>(c.tabT(), R1, stage_entry<true>(R1, 0, o), 1, in);
       const double wrow = c.pr.wrowR[o];
       const double pe = xn * wrow * d + 1e-10;
       const double fr = freq(c, o);
@@ -412,11 +467,14 @@ struct Large {
       c.X()[o] = wrow * fr * recip_nr(pe);
     }
     f = -bsum(c, fpart);  // barriers inside publish X
+    QT_STAMP(15);
     const double wl = prod_backward(c, c.tabT());
+    QT_STAMP(16);
     const double tr_g_rho = -(double)d * bsum(c, wl * bl);
     vec[c.t] = wl;
     __syncthreads();
     cd g = matrix_of(c, vec);
+    QT_STAMP(17);
     g.re = -g.re;
     g.im = -g.im;
     if (c.i == c.j) g.re -= tr_g_rho;
@@ -426,9 +484,15 @@ struct Large {
     __syncthreads();
     const cd* L = c.L();
     cd q{0.0, 0.0};
-    for (int k = c.pj; k < d; ++k) q = cadd(q, cmul(A[c.pi * LD + k], L[k * LD + c.pj]));
+#pragma unroll 8
+    for (int k = 0; k < d; ++k) {  // all k (L[k][pj] = 0 for k < pj): a fixed trip count can be pipelined
+      const cd u = A[c.pi * LD + k], v = L[k * LD + c.pj];
+      q.re = fma(u.re, v.re, fma(-u.im, v.im, q.re));
+      q.im = fma(u.re, v.im, fma(u.im, v.re, q.im));
+    }
     gt = 2.0 * (c.pkind == 2 ? q.im : q.re);
     __syncthreads();
+    QT_STAMP(18);
   }
 };
 

@@ -34,7 +34,9 @@ prof = torch.zeros((B * waves + 8, 32), dtype=torch.int64, device="cuda")
 eng.lib.qt_debug_set_prof.argtypes = [ctypes.c_void_p]
 assert eng.lib.qt_debug_set_prof(prof.data_ptr()) == 0
 names = {1: "make_ctx (load)", 2: "lin_invert", 3: "cholesky #1", 6: "psd_project (Jacobi)", 7: "cholesky #2",
-         8: "make_feasible end", 9: "nll_grad", 10: "BFGS + build + store"}
+         8: "make_feasible end", 9: "nll_grad", 10: "BFGS + build + store", 11: "(nll) entry", 12: "(nll) build L L^H",
+         13: "(nll) bloch_of", 14: "(nll) fwd stages 1..n-1", 15: "(nll) stage n + log", 16: "(nll) backward stages",
+         17: "(nll) matrix_of", 18: "(nll) Gt L + tail"}
 for _ in range(2):
     eng.mle_dev(cd_, out)
 eng.sync()
@@ -51,7 +53,7 @@ for label, sel in (("PD", ~nonpd), ("non-PD", nonpd)):
     q = p[sel]
     print(f"  {label}: mean total {np.mean(q.max(1) - q[:, 0]):.0f} clk")
     prev = q[:, 0]
-    for s in (1, 2, 3, 6, 7, 8, 9, 10):
+    for s in (1, 2, 3, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 9, 10):
         cur = q[:, s]
         have = cur > 0
         if not have.any():

@@ -233,3 +233,14 @@ def test_moment_sums_host_math_against_reference_radii(oracle):
         scale = var / mean
         radii = np.sqrt(sts.gamma(a=mean / scale, scale=scale).ppf(g["conf_levels"])) * np.sqrt(dim / 2)
         assert np.allclose(radii, g[key + "_gamma"], rtol=1e-9), key
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/qtomo.h is the drop-in boundary: it has to compile as C99 (no C++ or torch types in the
+    signatures) -- tests/host/abi_header_check.c calls a few entry points with plain pointers."""
+    import subprocess
+
+    src = os.path.join(ROOT, "tests", "host", "abi_header_check.c")
+    out = tmp_path / "abi_header_check.o"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", src, "-o", str(out)])
+    assert out.exists()

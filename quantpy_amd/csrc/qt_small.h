@@ -874,13 +874,15 @@ struct Small {
   // definite (its Cholesky factorisation runs through) no eigenvalue is below the clip, so
   // U max(v, 1e-15) U^dagger is the input itself (to rounding) and only the trace division is left.
   // Returns the projected element; if `xl` is non-null also the Cholesky parameter of the result.
-  __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out) {
+  __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out, double* lscale_out = nullptr) {
     int ok, neg, kneg;
     double x = cholesky_param(c, r, ok, &neg, &kneg);
     QT_STAMP(3);
     const double tr = gsum<G>(c.i == c.j ? r.re : 0.0);
     cd out{r.re / tr, r.im / tr};
-    x = x / sqrt(tr);  // L of r/tr
+    const double rst = 1.0 / sqrt(tr);
+    x = x * rst;  // L of r/tr
+    double lscale = rst;  // Bm() holds the factor of r, not of r/tr
     if (!__all(ok)) {
       cd proj;
       bool lifted = false;
@@ -900,6 +902,7 @@ struct Small {
         x2 = cholesky_param(c, proj, ok2);
       }
       QT_STAMP(7);
+      if (xl) lscale = 1.0;  // the whole wave went through the second factorisation: Bm() = factor of proj
       if (!ok) {
         out = proj;
         x = x2;
@@ -908,6 +911,7 @@ struct Small {
     }
     if (xl) *xl = x;
     if (ok_out) *ok_out = ok;
+    if (lscale_out) *lscale_out = lscale;
     return out;
   }
 
@@ -932,14 +936,27 @@ struct Small {
   }
 
   // ---- a9: NLL value and exact gradient at x (image = Aw).  Needs freq[] loaded.  Leaves L in Bm().
+  // `start` (first evaluation of a trial, at the Cholesky parameters of a matrix that is still at hand):
+  // rho(x) = L L^dagger / Tr is that matrix, and its factor already sits in Bm() up to the scale
+  // start->lscale, so L L^dagger is not formed again.
+  struct StartPoint {
+    cd rho;         // this lane's element of the normalised start matrix
+    double lscale;  // L(x) = lscale * Bm()
+  };
   __device__ static void nll_grad(const Ctx& c, double xl, double& f, double& gl, cd* rho_l = nullptr,
-                                  bool want_grad = true) {
+                                  bool want_grad = true, const StartPoint* start = nullptr) {
     double tr;
     QT_STAMP(11);
-    const cd m = build_llh(c, xl, tr);
+    cd m;
+    if (start) {
+      tr = gsum<G>(xl * xl);
+      m = cd{start->rho.re * tr, start->rho.im * tr};
+    } else {
+      m = build_llh(c, xl, tr);
+    }
     QT_STAMP(12);
     cd* A = c.A();
-    const cd rho_e{m.re / tr, m.im / tr};
+    const cd rho_e = start ? start->rho : cd{m.re / tr, m.im / tr};
     if (rho_l) *rho_l = rho_e;
     A[c.e] = rho_e;
     wave_sync();
@@ -1017,6 +1034,7 @@ struct Small {
       q.im = fma(u.re, v.im, fma(u.im, v.re, q.im));
     }
     gl = 2.0 * (c.pkind == 2 ? q.im : q.re);
+    if (start) gl *= start->lscale;
     wave_sync();
     QT_STAMP(18);
   }
@@ -1141,19 +1159,22 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
   S::load_freq(c, counts + (size_t)bb * pv.M);
   int ok;
   double xk;
+  typename S::StartPoint sp;
   if (init == 0) {
     S::load_image(c, pv.PinvT);
     double bl;
     const cd lin = S::lin_invert(c, bl);
     S::load_image(c, pv.Aw);  // (barrier inside: every wave is past its read of the left inverse)
-    S::make_feasible(c, lin, &xk, &ok);  // physical 'lin' estimate, already Cholesky-parametrised
+    sp.rho = S::make_feasible(c, lin, &xk, &ok, &sp.lscale);  // physical 'lin' estimate, Cholesky-parametrised
   } else {
     S::load_image(c, pv.Aw);
-    xk = S::cholesky_param(c, cd{c.i == c.j ? 1.0 / d : 0.0, 0.0}, ok);
+    sp.rho = cd{c.i == c.j ? 1.0 / d : 0.0, 0.0};
+    sp.lscale = 1.0;
+    xk = S::cholesky_param(c, sp.rho, ok);
   }
   double fk, gk;
   cd rho_l;  // L L^dagger / Tr at x_k: what the trial returns if BFGS does not move
-  S::nll_grad(c, xk, fk, gk, &rho_l);
+  S::nll_grad(c, xk, fk, gk, &rho_l, true, &sp);
   const double gnorm = gmax<G>(fabs(gk));
   const bool iterate = ok && (gnorm > gtol) && (0 < max_iter);
   int status = 0;
@@ -1344,21 +1365,24 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
   QT_STAMP(1);
   int ok;
   double xk;
+  typename S::StartPoint sp;
   if (init == 0) {
     S::load_image(c, pv.PinvT);
     double bl;
     const cd lin = S::lin_invert(c, bl);
     QT_STAMP(2);
     S::load_image(c, pv.Aw);
-    S::make_feasible(c, lin, &xk, &ok);
+    sp.rho = S::make_feasible(c, lin, &xk, &ok, &sp.lscale);
   } else {
     S::load_image(c, pv.Aw);
-    xk = S::cholesky_param(c, cd{c.i == c.j ? 1.0 / d : 0.0, 0.0}, ok);
+    sp.rho = cd{c.i == c.j ? 1.0 / d : 0.0, 0.0};
+    sp.lscale = 1.0;
+    xk = S::cholesky_param(c, sp.rho, ok);
   }
   QT_STAMP(8);
   double fk, gk;
   cd rho_l;
-  S::nll_grad(c, xk, fk, gk, &rho_l);
+  S::nll_grad(c, xk, fk, gk, &rho_l, true, &sp);
   const double gnorm = gmax<G>(fabs(gk));
   QT_STAMP(9);
   const bool iterate = live && ok && (gnorm > gtol) && (0 < max_iter);

@@ -310,7 +310,11 @@ struct Large {
     const double nrm = bsum(c, a.re * a.re + a.im * a.im);
     for (int sweep = 0; sweep < 30; ++sweep) {
       const double off = bsum(c, i != j ? a.re * a.re + a.im * a.im : 0.0);
-      if (!(off > 1e-28 * nrm)) break;  // uniform: every thread holds the same sums
+      QT_STAMP_VAL(20 + (sweep < 11 ? sweep : 11), (long long)(off / nrm * 1e30));
+      // off-diagonal norm <= 1e-13 of the matrix norm: by the Lipschitz bound of the clip the result moves by
+      // no more than that (~2e-14 here).  At d = 16, 32 most trials arrive at 1e-27 .. 1e-28 after their last
+      // useful sweep; a 1e-28 threshold sent them through one more (measured: profile build, slot 20+).
+      if (!(off > 1e-26 * nrm)) break;  // uniform: every thread holds the same sums
       // (the rounds use the unpadded pitch d: their pivot reads A[p][q] over lanes j spread over the
       //  banks through q = j ^ r, and padding the rows makes them collide instead)
       // Each round has d/2 rotations and d^2 elements that need two of them each: the first d threads

@@ -61,3 +61,9 @@ for label, sel in (("PD", ~nonpd), ("non-PD", nonpd)):
         dt = (cur - prev)[have]
         print(f"    {names[s]:24s} mean {dt.mean():9.0f}  max {dt.max():9.0f} clk")
         prev = np.where(have, cur, prev)
+
+if nonpd.any():
+    q = p[nonpd][:8]
+    print("Jacobi off^2/nrm^2 (x 1e30) at the start of each sweep, first non-PD trials:")
+    for row in q:
+        print("   ", [f"{v / 1e30:.1e}" for v in row[20:32] if v != 0])

@@ -172,7 +172,7 @@ struct ProcWG {
       const double n2 = act ? ar * ar + ai * ai : 0.0;
       const double off = block_sum<NT>((act && i != j) ? n2 : 0.0, sh.red);
       const double nrm = block_sum<NT>(n2, sh.red);
-      if (!(off > 1e-30 * nrm)) break;
+      if (!(off > 1e-26 * nrm)) break;  // off/norm <= 1e-13: the clip moves by no more than that (qt_large.h)
       for (int r = 0; r < DC - 1; ++r) {
         if (threadIdx.x < DC / 2) {
           const int t = threadIdx.x;

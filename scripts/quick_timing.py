@@ -1,6 +1,5 @@
 """Quick A/B aid: time 'lin'(physical) and 'mle' on the bench workload (n = 3, B = 1000) and save the
 results to gpurun_out/jtol_<tag>.npz so that two builds can be compared element by element."""
-import os
 import sys
 import numpy as np
 import torch

@@ -331,8 +331,10 @@ struct ProcWG {
 
 // counts[B][D][M] -> choi[B][DC][DC]; DC = D = 4^n.  pinvT = [D*M][DC*DC] complex (row r of the
 // design matrix along the slow axis so that threads read consecutive Choi-vector entries).
+// (second launch bound: at least 4 waves per SIMD, i.e. <= 128 VGPRs -- the ILP scheduling strategy the
+//  library is built with would otherwise spend 254 registers here and halve the occupancy)
 template <int DC>
-__global__ void __launch_bounds__(ProcWG<DC>::NT) k_lifp_batch(const int64_t* __restrict__ counts, int B, int M,
+__global__ void __launch_bounds__(ProcWG<DC>::NT, 4) k_lifp_batch(const int64_t* __restrict__ counts, int B, int M,
                                                               const double* __restrict__ pinvT, int cptp,
                                                               double* __restrict__ choi, int32_t* __restrict__ iters,
                                                               int32_t* __restrict__ status) {
@@ -405,7 +407,7 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT) k_lifp_batch(const int64_t* __
 // One workgroup per process; thread (i, j) owns Choi element C[i][j]; vectors are column-stacked
 // (v = col * DC + row, routines.py:59-61).  A = lifp [R][NE] complex, R = D * M.
 template <int DC>
-__global__ void __launch_bounds__(ProcWG<DC>::NT) k_pgdb_batch(const int64_t* __restrict__ counts, int B, int M,
+__global__ void __launch_bounds__(ProcWG<DC>::NT, 2) k_pgdb_batch(const int64_t* __restrict__ counts, int B, int M,
                                                               const double* __restrict__ lifp, int n_iter, double tol,
                                                               int stop_rule, double* __restrict__ choi,
                                                               int32_t* __restrict__ iters, int32_t* __restrict__ status) {
@@ -522,7 +524,7 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT) k_pgdb_batch(const int64_t* __
 // complex logarithm enters through its real part, as NumPy orders complex numbers by it).
 // One workgroup per chain; chain_out[c][t] = Choi matrix (row-major) after step t.
 template <int DC>
-__global__ void __launch_bounds__(ProcWG<DC>::NT) k_mhmc_process(const int64_t* __restrict__ counts, int C, int M,
+__global__ void __launch_bounds__(ProcWG<DC>::NT, 2) k_mhmc_process(const int64_t* __restrict__ counts, int C, int M,
                                                                 const double* __restrict__ lifp,
                                                                 const double* __restrict__ choi_init,
                                                                 const double* __restrict__ deltas,
@@ -591,7 +593,7 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT) k_mhmc_process(const int64_t* 
 
 // mode 0: Dykstra CPTP, 1: TP only, 2: CP only  (process.py:231-278)
 template <int DC>
-__global__ void __launch_bounds__(ProcWG<DC>::NT) k_cptp_project(const double* __restrict__ in, int B, int mode,
+__global__ void __launch_bounds__(ProcWG<DC>::NT, 4) k_cptp_project(const double* __restrict__ in, int B, int mode,
                                                                 int n_iter, double tol, double* __restrict__ out,
                                                                 int32_t* __restrict__ iters) {
   using W = ProcWG<DC>;

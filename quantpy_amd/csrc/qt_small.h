@@ -756,22 +756,28 @@ struct Small {
         ++neg;
       }
       if (!(mag > 1e-13)) neg = neg > 0 ? 99 : neg;  // NaN lands here too
-      const double rs = fast_rsqrt(mag > 1e-300 ? mag : 1e-300);  // 1 / |l_kk|
-      const cd lik{aik.re * rs, aik.im * rs};
-      if (j == k && i >= k) lmine = (i == k) ? cd{akk * rs, 0.0} : lik;
+      // In the sweep only 1 / a_kk is needed (a_ij -= s a_ik conj(a_jk) / |a_kk|); the square roots that turn
+      // the columns into L are taken once, for all columns in parallel, after the sweep.
+      const double safe = mag > 1e-300 ? mag : 1e-300;
       if (k + 1 < d) {
-        // a_ij -= s l_ik conj(l_jk), branch-free (both column reads are issued together; lanes outside
-        // the trailing block recompute their old value and store it again)
-        const double srs = pos ? -rs : rs;
-        const cd ljs{ajk.re * srs, ajk.im * srs};  // -s l_jk
+        const double inv = recip_nr(safe);
+        const double sinv = pos ? -inv : inv;
+        const cd ajs{ajk.re * sinv, ajk.im * sinv};  // -s a_jk / |a_kk|
         const bool upd = i > k && j > k;
-        const double nre = fma(lik.re, ljs.re, fma(lik.im, ljs.im, a.re));
-        const double nim = fma(lik.im, ljs.re, fma(-lik.re, ljs.im, a.im));
+        const double nre = fma(aik.re, ajs.re, fma(aik.im, ajs.im, a.re));
+        const double nim = fma(aik.im, ajs.re, fma(-aik.re, ajs.im, a.im));
         a.re = upd ? nre : a.re;
         a.im = upd ? nim : a.im;
-        A[c.e] = a;
+        A[c.e] = a;  // branch-free: lanes outside the trailing block store their old value again
         wave_sync();
       }
+    }
+    {
+      // lane (i, j), i >= j: its register still holds a_ij as it was when column j became the pivot column
+      const double dj = A[j * LD + j].re;
+      const double mj = fabs(dj);
+      const double rs = fast_rsqrt(mj > 1e-300 ? mj : 1e-300);  // 1 / |l_jj|
+      if (i >= j) lmine = (i == j) ? cd{dj * rs, 0.0} : cd{a.re * rs, a.im * rs};
     }
     ok = neg == 0;
     if (neg_out) *neg_out = neg;

@@ -990,12 +990,26 @@ struct Small {
         in = out;
       }
       QT_STAMP(14);
-      for (int o = c.l; o < c.M; o += G) {  // stage n fused with the log-likelihood terms
-        const double xn = stage_value<true>(c.tabT(), R1, tab[o], 1, in);
-        const double wrow = c.twrow[o];
-        const double pe = xn * wrow * d + 1e-10;
-        fpart += fr[o] * fast_log(pe);
-        rb[o] = wrow * fr[o] * recip_nr(pe);  // Y_n = w (.) r : A'^T r = K^T (w (.) r)
+      // stage n fused with the log-likelihood terms, two outputs per pass so that their LDS round trips
+      // (table entry -> operands) overlap; the second of a pair is a recomputation of the first when the
+      // row count runs out, and is not stored
+      for (int o = c.l; o < c.M; o += 2 * G) {
+        const int o2 = o + G;
+        const bool two = o2 < c.M;
+        const int oo = two ? o2 : o;
+        const int e0 = tab[o], e1 = tab[oo];
+        const double x0 = stage_value<true>(c.tabT(), R1, e0, 1, in);
+        const double x1 = stage_value<true>(c.tabT(), R1, e1, 1, in);
+        const double w0 = c.twrow[o], w1 = c.twrow[oo];
+        const double f0 = fr[o], f1 = fr[oo];
+        const double p0 = x0 * w0 * d + 1e-10, p1 = x1 * w1 * d + 1e-10;
+        const double l0 = fast_log(p0), l1 = fast_log(p1);
+        fpart += f0 * l0;
+        rb[o] = w0 * f0 * recip_nr(p0);  // Y_n = w (.) r : A'^T r = K^T (w (.) r)
+        if (two) {
+          fpart += f1 * l1;
+          rb[o2] = w1 * f1 * recip_nr(p1);
+        }
       }
       f = -gsum<G>(fpart);
       wave_sync();

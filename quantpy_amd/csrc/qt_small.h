@@ -525,14 +525,44 @@ struct Small {
 
   // counts of this trial -> freq[] in LDS (counts / sum(counts): state.py:193, :227).  For a product
   // POVM the frequencies are stored in R-order and the one-qubit tables are staged next to them.
-  __device__ static void load_freq(const Ctx& c, const int64_t* counts) {
-    // one coalesced pass over the counts (the only HBM latency of the trial): values parked in rbuf
+  // The counts are the only HBM read of a trial.  Issued at the very top of the kernel (before the
+  // workgroup stages its tables and meets at the barrier of make_ctx) their latency runs in the shadow
+  // of that set-up; up to 4 values per lane are held in registers until load_freq picks them up.
+  struct Prefetch {
+    int64_t v[4];
+    bool ok;
+  };
+  __device__ __forceinline__ static void prefetch_counts(Prefetch& pf, const int64_t* counts, int M) {
+    const int l = (threadIdx.x & 63) % G;
+    pf.ok = M <= 4 * G;
+    if (pf.ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = l + q * G;
+        pf.v[q] = counts[m < M ? m : M - 1];
+      }
+    }
+  }
+  __device__ static void load_freq(const Ctx& c, const int64_t* counts, const Prefetch* pf = nullptr) {
+    // one coalesced pass over the counts: values parked in rbuf
     double part = 0.0;
     double* raw = c.rbuf();
-    for (int m = c.l; m < c.M; m += G) {
-      const double v = (double)counts[m];
-      raw[m] = v;
-      part += v;
+    if (pf && pf->ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = c.l + q * G;
+        if (m < c.M) {
+          const double v = (double)pf->v[q];
+          raw[m] = v;
+          part += v;
+        }
+      }
+    } else {
+      for (int m = c.l; m < c.M; m += G) {
+        const double v = (double)counts[m];
+        raw[m] = v;
+        part += v;
+      }
     }
     if (c.prod()) {
       for (int e = c.l; e < 4 * c.pv.pr.R1; e += G) {
@@ -1072,13 +1102,15 @@ __global__ void __launch_bounds__(256) k_lin_batch(PovmView pv, const int64_t* _
   using S = Small<NQ, ALDS>;
   extern __shared__ double smem[];
   typename S::Ctx c;
-  S::make_ctx(c, smem, pv);
   bool live;
   const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;  // padding groups recompute the last trial; nothing is stored
+  typename S::Prefetch pf;
+  S::prefetch_counts(pf, counts + (size_t)bb * pv.M, pv.M);
+  S::make_ctx(c, smem, pv);
   QT_STAMP(0);
   S::load_image(c, pv.PinvT);
-  S::load_freq(c, counts + (size_t)bb * pv.M);
+  S::load_freq(c, counts + (size_t)bb * pv.M, &pf);
   QT_STAMP(1);
   double bl;
   cd r = S::lin_invert(c, bl);
@@ -1172,11 +1204,13 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
   constexpr int D = S::D, G = S::G, d = S::d;
   extern __shared__ double smem[];
   typename S::Ctx c;
-  S::make_ctx(c, smem, pv);
   bool live;
   const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;
-  S::load_freq(c, counts + (size_t)bb * pv.M);
+  typename S::Prefetch pf;
+  S::prefetch_counts(pf, counts + (size_t)bb * pv.M, pv.M);
+  S::make_ctx(c, smem, pv);
+  S::load_freq(c, counts + (size_t)bb * pv.M, &pf);
   int ok;
   double xk;
   typename S::StartPoint sp;
@@ -1376,12 +1410,14 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
   constexpr int D = S::D, G = S::G, d = S::d;
   extern __shared__ double smem[];
   typename S::Ctx c;
-  S::make_ctx(c, smem, pv);
   bool live;
   const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;
+  typename S::Prefetch pf;
+  S::prefetch_counts(pf, counts + (size_t)bb * pv.M, pv.M);
+  S::make_ctx(c, smem, pv);
   QT_STAMP(0);
-  S::load_freq(c, counts + (size_t)bb * pv.M);
+  S::load_freq(c, counts + (size_t)bb * pv.M, &pf);
   QT_STAMP(1);
   int ok;
   double xk;

@@ -293,6 +293,61 @@ __global__ void __launch_bounds__(256) k_born(const double* __restrict__ AT, int
   }
 }
 
+// ---- a4 on the FP64 matrix cores: P[B x M] = d * Bloch[B x D] * A^T[D x M], clipped to [0, 1] ------------
+// Batched over states the Born rule is a GEMM with a small fixed right-hand side.  A^T (padded to 16-column
+// tiles) is staged once per workgroup in LDS (112 KB at n = 3: one workgroup of 8 waves per CU); a wavefront
+// takes 16 states at a time, holds their Bloch rows as the MFMA A-operand (D / 4 registers), and walks the
+// M / 16 column tiles with v_mfma_f64_16x16x4_f64, one ds_read_b64 per MFMA.  What is left is the stream:
+// 8 (D + M) bytes per state.  (Operand layout as in k_gemm above.)
+template <int DD>
+__global__ void __launch_bounds__(512) k_born_mfma(const double* __restrict__ AT, int M, int Mp, int dscale,
+                                                   const double* __restrict__ bloch, int B, double* __restrict__ p) {
+  // [DD][Mp]; Mp is M rounded up to whole 16-column tiles and then to 16 mod 32, so that the four rows one
+  // B-operand read touches (128 bytes each) alternate between the two halves of the 64 LDS banks
+  extern __shared__ double s_at[];
+  for (int e = threadIdx.x; e < DD * Mp; e += blockDim.x) {
+    const int k = e / Mp, m = e % Mp;
+    s_at[e] = m < M ? AT[(size_t)k * M + m] : 0.0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int ngroups = (B + 15) / 16, gstride = gridDim.x * nwave;
+  const int ntiles = (M + 15) / 16;
+  auto load_rows = [&](int g, double (&a)[DD / 4]) {
+    const int row = g * 16 + r16;
+#pragma unroll
+    for (int sidx = 0; sidx < DD / 4; ++sidx) a[sidx] = (g < ngroups && row < B) ? bloch[(size_t)row * DD + 4 * sidx + kq] : 0.0;
+  };
+  double a[DD / 4], an[DD / 4];
+  int g = blockIdx.x * nwave + wave;
+  load_rows(g, a);
+  for (; g < ngroups; g += gstride) {
+    load_rows(g + gstride, an);  // the next group's rows are in flight while this one is multiplied
+    for (int ct = 0; ct < ntiles; ++ct) {
+      const int c0 = ct * 16;
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int sidx = 0; sidx < DD / 4; ++sidx)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], s_at[(4 * sidx + kq) * Mp + c0 + r16], acc, 0, 0, 0);
+      const int col = c0 + r16;
+      if (col < M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int orow = g * 16 + kq + 4 * r;
+          if (orow < B) {
+            double v = acc[r] * dscale;
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            p[(size_t)orow * M + col] = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < DD / 4; ++sidx) a[sidx] = an[sidx];
+  }
+}
+
 // ---- a3 (any n): qobj.py:126-135 / :109-118, one thread per output element --------------------
 __global__ void k_bloch_from_mat(int nq, const double* __restrict__ mat, int B, double* __restrict__ bloch) {
   const int d = 1 << nq;

@@ -322,26 +322,43 @@ __global__ void __launch_bounds__(512) k_born_mfma(const double* __restrict__ AT
   double a[DD / 4], an[DD / 4];
   int g = blockIdx.x * nwave + wave;
   load_rows(g, a);
-  for (; g < ngroups; g += gstride) {
-    load_rows(g + gstride, an);  // the next group's rows are in flight while this one is multiplied
-    for (int ct = 0; ct < ntiles; ++ct) {
-      const int c0 = ct * 16;
-      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  // B-operand of one column tile: DD / 4 values per lane, read together so that the MFMA chain that
+  // follows runs back to back (read-then-multiply one at a time leaves the LDS latency between MFMAs)
+  auto load_tile = [&](int ct, double (&bt)[DD / 4]) {
+    const int c0 = (ct < ntiles ? ct : ntiles - 1) * 16;
 #pragma unroll
-      for (int sidx = 0; sidx < DD / 4; ++sidx)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], s_at[(4 * sidx + kq) * Mp + c0 + r16], acc, 0, 0, 0);
-      const int col = c0 + r16;
-      if (col < M) {
+    for (int sidx = 0; sidx < DD / 4; ++sidx) bt[sidx] = s_at[(4 * sidx + kq) * Mp + c0 + r16];
+  };
+  auto multiply_store = [&](int ct, const double (&bt)[DD / 4]) {
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int orow = g * 16 + kq + 4 * r;
-          if (orow < B) {
-            double v = acc[r] * dscale;
-            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-            p[(size_t)orow * M + col] = v;
-          }
+    for (int sidx = 0; sidx < DD / 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], bt[sidx], acc, 0, 0, 0);
+    const int col = ct * 16 + r16;
+    if (ct < ntiles && col < M) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = g * 16 + kq + 4 * r;
+        if (orow < B) {
+          double v = acc[r] * dscale;
+          v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+          p[(size_t)orow * M + col] = v;
         }
       }
+    }
+  };
+  for (; g < ngroups; g += gstride) {
+    load_rows(g + gstride, an);  // the next group's rows are in flight while this one is multiplied
+    double b0[DD / 4], b1[DD / 4];
+    load_tile(0, b0);
+    for (int ct = 0; ct < ntiles; ct += 2) {
+      load_tile(ct + 1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply_store(ct, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_tile(ct + 2, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply_store(ct + 1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int sidx = 0; sidx < DD / 4; ++sidx) a[sidx] = an[sidx];

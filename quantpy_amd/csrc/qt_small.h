@@ -142,16 +142,14 @@ __device__ __forceinline__ double fast_log(double x) {
   double sq = num * r;
   sq = fma(r, fma(-sq, den, num), sq);  // s = num / den, correctly rounded up to the last bit
   const double z = sq * sq;
-  double pl = 1.0 / 21.0;
-  pl = fma(pl, z, 1.0 / 19.0);
-  pl = fma(pl, z, 1.0 / 17.0);
-  pl = fma(pl, z, 1.0 / 15.0);
-  pl = fma(pl, z, 1.0 / 13.0);
-  pl = fma(pl, z, 1.0 / 11.0);
-  pl = fma(pl, z, 1.0 / 9.0);
-  pl = fma(pl, z, 1.0 / 7.0);
-  pl = fma(pl, z, 1.0 / 5.0);
-  pl = fma(pl, z, 1.0 / 3.0);
+  // P(z) = 1/3 + z/5 + ... + z^9/21, Estrin's scheme: pairs, then powers z^2, z^4, z^8 (dependency depth 5
+  // instead of the 10 of Horner's rule)
+  const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+  const double q0 = fma(z, 1.0 / 5.0, 1.0 / 3.0), q1 = fma(z, 1.0 / 9.0, 1.0 / 7.0);
+  const double q2 = fma(z, 1.0 / 13.0, 1.0 / 11.0), q3 = fma(z, 1.0 / 17.0, 1.0 / 15.0);
+  const double q4 = fma(z, 1.0 / 21.0, 1.0 / 19.0);
+  const double r0 = fma(z2, q1, q0), r1 = fma(z2, q3, q2);
+  const double pl = fma(z8, q4, fma(z4, r1, r0));
   const double lm = fma(sq + sq, pl * z, sq + sq);  // 2 s (1 + z P(z))
   const double ed = (double)e;
   return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));  // e ln2 (hi + lo) + log m
@@ -863,13 +861,19 @@ struct Small {
     for (int k = 1; k <= 7 && !done; ++k) {
       Ai[c.e] = b;
       wave_sync();
-      cd n{0.0, 0.0};
+      cd n{0.0, 0.0}, n2{0.0, 0.0};  // even / odd terms: two dependency chains per component
 #pragma unroll
-      for (int q = 0; q < d; ++q) {
+      for (int q = 0; q < d; q += 2) {
         const cd u = Ai[i * LD + q], v = Ai[j * LD + q];
         n.re = fma(u.re, v.re, fma(u.im, v.im, n.re));
         n.im = fma(u.im, v.re, fma(-u.re, v.im, n.im));
+        if (q + 1 < d) {
+          const cd u2 = Ai[i * LD + q + 1], v2 = Ai[j * LD + q + 1];
+          n2.re = fma(u2.re, v2.re, fma(u2.im, v2.im, n2.re));
+          n2.im = fma(u2.im, v2.re, fma(-u2.re, v2.im, n2.im));
+        }
       }
+      n = cadd(n, n2);
       wave_sync();
       const double pur = gsum<G>(n.re * n.re + n.im * n.im);
       b = cscale(n, fast_rsqrt(pur));
@@ -1320,9 +1324,12 @@ __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx
           // H <- (I - rho s y^T) H (I - rho y s^T) + rho s s^T, expanded with u = H y
           vec[c.l] = yk;
           wave_sync();
-          double u = 0.0;
+          // four partial sums: a lone wave pays ~16 ns per DEPENDENT FP64 instruction under load
+          // (profiles/round1_v14_ubench_valu_f64.txt); a 64-term chain would be 1 us of latency
+          double uu[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int k = 0; k < D; ++k) u += H[k] * vec[k];
+          for (int k = 0; k < D; ++k) uu[k & 3] = fma(H[k], vec[k], uu[k & 3]);
+          double u = (uu[0] + uu[1]) + (uu[2] + uu[3]);
           const double yhy = gsum<G>(yk * u);
           wave_sync();
           double* ubuf = reinterpret_cast<double*>(c.A());  // 2 D doubles: u | s
@@ -1339,9 +1346,10 @@ __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx
           } else {
             vec[c.l] = gk;
             wave_sync();
-            double hp = 0.0;
+            double hh[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < D; ++k) hp += H[k] * vec[k];
+            for (int k = 0; k < D; ++k) hh[k & 3] = fma(H[k], vec[k], hh[k & 3]);
+            const double hp = (hh[0] + hh[1]) + (hh[2] + hh[3]);
             wave_sync();
             pk = -hp;
             ls.start(fk, old_old, gsum<G>(gk * pk), &stp);

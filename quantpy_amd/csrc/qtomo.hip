@@ -563,6 +563,11 @@ int qt_born_probs(qt_handle_t* h, const double* bloch, int B, double* p, int fla
   double* dout;
   if (int r = stage_in(h, h->in0, bloch, (size_t)B * h->D, flags, &din)) return r;
   if (int r = stage_out(h, h->out0, p, (size_t)B * h->M, flags, &dout)) return r;
+  if (h->nq >= 4 && h->prod.enabled) {  // factorised contraction, one workgroup per state
+    QT_LAUNCH_LARGE(qt::k_born_large, B, h->M, h->prod.R1, (h->view(), din, B, dout));
+    if (int r = fetch_out(h, dout, p, (size_t)B * h->M, flags)) return r;
+    return finish(h, flags);
+  }
   const int gx = (h->M + 255) / 256;
   int Mp = (h->M + 15) & ~15;
   if ((Mp & 31) != 16) Mp += 16;  // LDS pitch: 16 mod 32 doubles (see k_born_mfma)

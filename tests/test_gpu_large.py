@@ -109,3 +109,26 @@ def test_state_tomograph_api_n4(qp, oracle):
     mle = t.point_estimate("mle")
     ref, ri = oracle.mle_estimate(t.results, np.array(t.povm_matrix), return_info=True, solver="port")
     assert t.mle_info["nit"] == ri["nit"] and abs(oracle.infidelity(ref, mle.matrix)) < 1e-6
+
+
+@pytest.mark.parametrize("n", [4, 5])
+def test_born_probabilities_product_path(qp, oracle, n):
+    """qt_born_probs at n = 4, 5 runs the factorised contraction (k_born_large); against the dense einsum of
+    state.py:109-110 on the same tensor, output in the caller's (S, K) order."""
+    rng = np.random.default_rng(40 + n)
+    d = 2**n
+    eng = qp.get_engine(n)
+    for povm_name in ("proj-set", "sic"):
+        povm = qp.generate_measurement_matrix(povm_name, n)
+        eng.set_povm(povm, np.ones(povm.shape[0]) * 1000.0)
+        states = []
+        for _ in range(3):
+            g = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+            r = g @ g.conj().T
+            states.append(oracle.bloch_from_matrix(r / np.trace(r).real))
+        bl = np.stack(states)
+        got = eng.born_probs(bl)
+        want = np.clip(np.einsum("skd,bd->bsk", np.asarray(povm), bl) * d, 0, 1)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 1e-14, (n, povm_name)
+        assert np.abs(got.sum(-1) - 1).max() < 1e-12

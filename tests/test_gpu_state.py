@@ -247,3 +247,26 @@ def test_hs_distance(oracle):
         got = eng.hs_dist(m, m[0])
         want = [oracle.hs_dst(x, m[0]) for x in m]
         assert np.abs(got - want).max() < 1e-12 and got[5] == 0 and got[0] == 0
+
+
+def test_born_probabilities_large_batches(oracle):
+    """Batched Born rule around the batch size where qt_born_probs switches to the matrix-core kernel
+    (B >= 4096; ragged last group of 16 states), product tensor and plain array alike, against einsum."""
+    import quantpy_amd as qp
+
+    rng = np.random.default_rng(77)
+    for n in (1, 2, 3):
+        d, D = 2**n, 4**n
+        eng = _eng(n)
+        for povm_name in ("proj-set", "sic"):
+            prod = qp.generate_measurement_matrix(povm_name, n)
+            dense = np.array(prod)
+            for B in (2048, 4100, 5003):
+                bl = rng.standard_normal((B, D)) * 0.05
+                bl[:, 0] = 1.0 / d
+                want = np.clip(np.einsum("skd,bd->bsk", dense, bl) * d, 0, 1)
+                for pv in (prod, dense):
+                    eng.set_povm(pv, np.ones(dense.shape[0]) * 100.0)
+                    got = eng.born_probs(bl)
+                    assert got.shape == want.shape
+                    assert np.abs(got - want).max() < 1e-14, (n, povm_name, B, type(pv).__name__)

@@ -299,11 +299,14 @@ __global__ void __launch_bounds__(256) k_born(const double* __restrict__ AT, int
 // takes 16 states at a time, holds their Bloch rows as the MFMA A-operand (D / 4 registers), and walks the
 // M / 16 column tiles with v_mfma_f64_16x16x4_f64, one ds_read_b64 per MFMA.  What is left is the stream:
 // 8 (D + M) bytes per state.  (Operand layout as in k_gemm above.)
+//
+// 16 wavefronts per workgroup (4 per SIMD, 71 VGPRs): the other waves of a SIMD cover the operand latencies
+// (an 8-wave version with software prefetch and double-buffered operand tiles measured 59 us where this
+// one takes 51).  LDS pitch Mp = 16 mod 32 doubles: the four rows of one B-operand read (128 bytes each)
+// alternate between the two halves of the 64 banks.
 template <int DD>
-__global__ void __launch_bounds__(512) k_born_mfma(const double* __restrict__ AT, int M, int Mp, int dscale,
-                                                   const double* __restrict__ bloch, int B, double* __restrict__ p) {
-  // [DD][Mp]; Mp is M rounded up to whole 16-column tiles and then to 16 mod 32, so that the four rows one
-  // B-operand read touches (128 bytes each) alternate between the two halves of the 64 LDS banks
+__global__ void __launch_bounds__(1024) k_born_mfma(const double* __restrict__ AT, int M, int Mp, int dscale,
+                                                      const double* __restrict__ bloch, int B, double* __restrict__ p) {
   extern __shared__ double s_at[];
   for (int e = threadIdx.x; e < DD * Mp; e += blockDim.x) {
     const int k = e / Mp, m = e % Mp;
@@ -312,56 +315,33 @@ __global__ void __launch_bounds__(512) k_born_mfma(const double* __restrict__ AT
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
-  const int ngroups = (B + 15) / 16, gstride = gridDim.x * nwave;
-  const int ntiles = (M + 15) / 16;
-  auto load_rows = [&](int g, double (&a)[DD / 4]) {
+  const int ngroups = (B + 15) / 16, ntiles = (M + 15) / 16;
+  for (int g = blockIdx.x * nwave + wave; g < ngroups; g += gridDim.x * nwave) {
     const int row = g * 16 + r16;
+    double a[DD / 4];
 #pragma unroll
-    for (int sidx = 0; sidx < DD / 4; ++sidx) a[sidx] = (g < ngroups && row < B) ? bloch[(size_t)row * DD + 4 * sidx + kq] : 0.0;
-  };
-  double a[DD / 4], an[DD / 4];
-  int g = blockIdx.x * nwave + wave;
-  load_rows(g, a);
-  // B-operand of one column tile: DD / 4 values per lane, read together so that the MFMA chain that
-  // follows runs back to back (read-then-multiply one at a time leaves the LDS latency between MFMAs)
-  auto load_tile = [&](int ct, double (&bt)[DD / 4]) {
-    const int c0 = (ct < ntiles ? ct : ntiles - 1) * 16;
+    for (int sidx = 0; sidx < DD / 4; ++sidx) a[sidx] = row < B ? bloch[(size_t)row * DD + 4 * sidx + kq] : 0.0;
+    for (int ct = 0; ct < ntiles; ++ct) {
+      const int c0 = ct * 16;
+      double bt[DD / 4];
 #pragma unroll
-    for (int sidx = 0; sidx < DD / 4; ++sidx) bt[sidx] = s_at[(4 * sidx + kq) * Mp + c0 + r16];
-  };
-  auto multiply_store = [&](int ct, const double (&bt)[DD / 4]) {
-    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int sidx = 0; sidx < DD / 4; ++sidx) bt[sidx] = s_at[(4 * sidx + kq) * Mp + c0 + r16];
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int sidx = 0; sidx < DD / 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], bt[sidx], acc, 0, 0, 0);
-    const int col = ct * 16 + r16;
-    if (ct < ntiles && col < M) {
+      for (int sidx = 0; sidx < DD / 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], bt[sidx], acc, 0, 0, 0);
+      const int col = c0 + r16;
+      if (col < M) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int orow = g * 16 + kq + 4 * r;
-        if (orow < B) {
-          double v = acc[r] * dscale;
-          v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-          p[(size_t)orow * M + col] = v;
+        for (int r = 0; r < 4; ++r) {
+          const int orow = g * 16 + kq + 4 * r;
+          if (orow < B) {
+            double v = acc[r] * dscale;
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            p[(size_t)orow * M + col] = v;
+          }
         }
       }
     }
-  };
-  for (; g < ngroups; g += gstride) {
-    load_rows(g + gstride, an);  // the next group's rows are in flight while this one is multiplied
-    double b0[DD / 4], b1[DD / 4];
-    load_tile(0, b0);
-    for (int ct = 0; ct < ntiles; ct += 2) {
-      load_tile(ct + 1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply_store(ct, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_tile(ct + 2, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply_store(ct + 1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int sidx = 0; sidx < DD / 4; ++sidx) a[sidx] = an[sidx];
   }
 }
 

@@ -573,23 +573,23 @@ int qt_born_probs(qt_handle_t* h, const double* bloch, int B, double* p, int fla
   if ((Mp & 31) != 16) Mp += 16;  // LDS pitch: 16 mod 32 doubles (see k_born_mfma)
   const size_t at_bytes = (size_t)h->D * Mp * sizeof(double);
   if (h->D <= 64 && at_bytes <= 128 * 1024 && B >= 4096) {
-    // batched: the matrix-core kernel, one persistent workgroup per CU (A^T lives in its LDS)
-    int grid = (B + 16 * 8 - 1) / (16 * 8);
+    // batched: the matrix-core kernel, one persistent 16-wave workgroup per CU (A^T lives in its LDS)
+    int grid = (B + 16 * 16 - 1) / (16 * 16);
     if (grid > 256) grid = 256;
     switch (h->D) {
       case 4:
         if (int r = allow_big_lds(qt::k_born_mfma<4>, at_bytes)) return r;
-        hipLaunchKernelGGL(qt::k_born_mfma<4>, dim3(grid), dim3(512), at_bytes, h->stream, h->AT.as<double>(), h->M, Mp, h->d,
+        hipLaunchKernelGGL(qt::k_born_mfma<4>, dim3(grid), dim3(1024), at_bytes, h->stream, h->AT.as<double>(), h->M, Mp, h->d,
                            din, B, dout);
         break;
       case 16:
         if (int r = allow_big_lds(qt::k_born_mfma<16>, at_bytes)) return r;
-        hipLaunchKernelGGL(qt::k_born_mfma<16>, dim3(grid), dim3(512), at_bytes, h->stream, h->AT.as<double>(), h->M, Mp, h->d,
+        hipLaunchKernelGGL(qt::k_born_mfma<16>, dim3(grid), dim3(1024), at_bytes, h->stream, h->AT.as<double>(), h->M, Mp, h->d,
                            din, B, dout);
         break;
       default:
         if (int r = allow_big_lds(qt::k_born_mfma<64>, at_bytes)) return r;
-        hipLaunchKernelGGL(qt::k_born_mfma<64>, dim3(grid), dim3(512), at_bytes, h->stream, h->AT.as<double>(), h->M, Mp, h->d,
+        hipLaunchKernelGGL(qt::k_born_mfma<64>, dim3(grid), dim3(1024), at_bytes, h->stream, h->AT.as<double>(), h->M, Mp, h->d,
                            din, B, dout);
         break;
     }

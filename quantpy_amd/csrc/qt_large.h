@@ -47,8 +47,8 @@ struct Large {
   static constexpr int oVec = oL + MAT;        // [D]
   static constexpr int oLam = oVec + D;        // [d]
   static constexpr int oRed = oLam + d;        // [32] reduction scratch
-  static constexpr int oRot = oRed + 32;       // Jacobi rotations of the current round: cos [d], w [d] complex
-  static constexpr int oTab = oRot + 3 * d + (d & 1);  // tabT [R1][4], tabP [R1][4]
+  static constexpr int oRot = oRed + 32;       // Jacobi rotations of this round and the next: 2 x (cos [d], w [d] complex)
+  static constexpr int oTab = oRot + 6 * d;    // tabT [R1][4], tabP [R1][4]
   __host__ __device__ static int x_doubles(int M) { return (M > MAT ? M : MAT) + (M & 1); }
   __host__ __device__ static int y_doubles(int M, int R1) {
     int y = (M / R1) * 4;  // R1^(n-1) * 4: the largest stage that lands in Y
@@ -72,8 +72,6 @@ struct Large {
     __device__ __forceinline__ double* vec() const { return sm + oVec; }
     __device__ __forceinline__ double* lam() const { return sm + oLam; }
     __device__ __forceinline__ double* red() const { return sm + oRed; }
-    __device__ __forceinline__ double* rot_c() const { return sm + oRot; }
-    __device__ __forceinline__ cd* rot_w() const { return reinterpret_cast<cd*>(sm + oRot + d); }
     __device__ __forceinline__ double* tabT() const { return sm + oTab; }
     __device__ __forceinline__ double* tabP() const { return sm + oTab + 4 * pr.R1; }
     __device__ __forceinline__ double* X() const { return sm + oTab + 8 * pr.R1; }
@@ -273,16 +271,18 @@ struct Large {
   // alternating; tb = tabT (A^T y) or tabP (A^+ f).
   __device__ static double prod_backward(const Ctx& c, const double* tb) {
     const int R1 = c.pr.R1;
-    const double* in = c.X();
-    double* bufs[2] = {c.Y(), c.X()};
-    int which = 0;
+    // (X / Y picked by offset from the LDS base, not through an array of pointers: see psd_project)
+    const int xo = (int)(c.X() - c.sm), yo = (int)(c.Y() - c.sm);
+    int in_off = xo, which = 0;
     for (int q = NQ; q >= 2; --q) {
       const int lk = 2 * (NQ - q);
       const int n_out = ipow(R1, q - 1) * 4 << lk;
-      stage<false>(c, tb, lk, n_out, in, bufs[which]);
-      in = bufs[which];
+      const int out_off = which ? xo : yo;
+      stage<false>(c, tb, lk, n_out, c.sm + in_off, c.sm + out_off);
+      in_off = out_off;
       which ^= 1;
     }
+    const double* in = c.sm + in_off;
     const double r = stage_value<false>(tb, R1, stage_entry<false>(R1, 2 * (NQ - 1), c.t), 1 << (2 * (NQ - 1)), in);
     __syncthreads();
     return r;
@@ -300,14 +300,54 @@ struct Large {
     return r;
   }
 
-  // ---- a7: Jacobi eigenvalue clip (XOR order; one LDS round trip + one barrier pair per round) ---
+  // ---- a7: Jacobi eigenvalue clip (XOR order) ------------------------------------------------------
+  // One round = d/2 disjoint rotations; element (i, j) needs the rotation of its column pair (j, j ^ r)
+  // and of its row pair (i, i ^ r).  The d rotations of a round hang on 3 d/2 pivot elements only, so they
+  // are computed ONE ROUND AHEAD: while everybody applies round r, the first 2 d threads bring the
+  // pivots of round r + 1 up to date themselves (thread k < d the diagonal element (k, k), thread d + k
+  // the off-diagonal one of k's next pair; same arithmetic as the owners of those elements), turn them
+  // into cos / w and leave them in the other of two small LDS tables; the barrier of round r + 1 publishes
+  // them.  One barrier per round and nobody waits for a rotation: v9 computed them between two barriers
+  // with all other wavefronts idle (~2500 clk per round at d = 32); each wavefront computing all d
+  // rotations for itself was tried and is bound by the 4 x 16 copies of that arithmetic instead (slower).
+  // The A image alternates between two buffers (the Y overlay and the L region, which holds nothing live
+  // here: the factorisation that called us has failed); V never goes to LDS: V[i][j ^ r] is in lane l ^ r.
+  __device__ __forceinline__ static cd rotate_elem(cd a, cd a_c, cd a_r, cd a_x, double cj, cd wj, double ci, cd wi) {
+    // A'_ij = ci (a_ij cj + a_i,pj wj) + conj(wi) (a_pi,j cj + a_pi,pj wj)
+    const cd t0 = cadd(cscale(a, cj), cmul(a_c, wj));
+    const cd t1 = cadd(cscale(a_r, cj), cmul(a_x, wj));
+    return cadd(cscale(t0, ci), cmulc(t1, wi));
+  }
+  // rotation of index k in the round that pairs k with pk, already signed for k's side:
+  // J[pk][k] = -conj(w) if k is the lower index, else w
+  __device__ __forceinline__ static void signed_rotation(int k, int pk, double a_kk, double a_pkpk, cd a_pq, double* rc, cd* rw) {
+    double cs;
+    cd w;
+    rotation(k < pk ? a_kk : a_pkpk, k < pk ? a_pkpk : a_kk, a_pq, cs, w);
+    if (k < pk) w = cd{-w.re, w.im};
+    rc[k] = cs;
+    rw[k] = w;
+  }
   __device__ static cd psd_project(const Ctx& c, cd a, double eps) {
     const int i = c.i, j = c.j;
-    cd* Ai = c.Aimg();
+    // (buffers are picked by OFFSET from the LDS base: with an array of two pointers indexed at run time the
+    //  compiler loses the address space and emits flat_load / flat_store for every access in the loop)
+    const int img_off[2] = {(int)(c.Y() - c.sm), oL};
+    cd* img1 = reinterpret_cast<cd*>(c.sm + oL);
     cd* Vi = c.Vimg();
     cd v{i == j ? 1.0 : 0.0, 0.0};
     if (i == j) a.im = 0.0;
     const double nrm = bsum(c, a.re * a.re + a.im * a.im);
+    // (the rounds use the unpadded pitch d: their pivot reads A[p][q] over lanes j spread over the
+    //  banks through q = j ^ r, and padding the rows makes them collide instead)
+    img1[c.t] = a;
+    __syncthreads();
+    if (c.t < d) {  // rotations of the very first round, from the input itself
+      const int k = c.t, pk = k ^ 1, p = k < pk ? k : pk, q = k < pk ? pk : k;
+      signed_rotation(k, pk, img1[k * d + k].re, img1[pk * d + pk].re, img1[p * d + q], c.sm + oRot,
+                      reinterpret_cast<cd*>(c.sm + oRot + d));
+    }
+    int which = 0, cur = 0;
     for (int sweep = 0; sweep < 30; ++sweep) {
       const double off = bsum(c, i != j ? a.re * a.re + a.im * a.im : 0.0);
       QT_STAMP_VAL(20 + (sweep < 11 ? sweep : 11), (long long)(off / nrm * 1e30));
@@ -315,36 +355,32 @@ struct Large {
       // no more than that (~2e-14 here).  At d = 16, 32 most trials arrive at 1e-27 .. 1e-28 after their last
       // useful sweep; a 1e-28 threshold sent them through one more (measured: profile build, slot 20+).
       if (!(off > 1e-26 * nrm)) break;  // uniform: every thread holds the same sums
-      // (the rounds use the unpadded pitch d: their pivot reads A[p][q] over lanes j spread over the
-      //  banks through q = j ^ r, and padding the rows makes them collide instead)
-      // Each round has d/2 rotations and d^2 elements that need two of them each: the first d threads
-      // compute them once (index k gets the rotation of its pair, already signed for k's side) and
-      // everybody else picks up cos / w from LDS instead of redoing 2 x ~30 FP64 instructions.
-      double* rc = c.rot_c();
-      cd* rw = c.rot_w();
       for (int r = 1; r < d; ++r) {
+        const int rn = r + 1 < d ? r + 1 : 1;  // the round after this one (round 1 of the next sweep)
+        cd* Ai = reinterpret_cast<cd*>(c.sm + (which ? img_off[1] : img_off[0]));
+        const double* rc = c.sm + oRot + (cur ? 3 * d : 0);  // cos [d], w [d] complex, twice
+        const cd* rw = reinterpret_cast<const cd*>(rc + d);
+        double* nc = c.sm + oRot + (cur ? 0 : 3 * d);
+        cd* nw = reinterpret_cast<cd*>(nc + d);
+        which ^= 1;
+        cur ^= 1;
         Ai[c.t] = a;
-        Vi[c.t] = v;
         __syncthreads();
         const int pj = j ^ r, pi = i ^ r;
-        if (c.t < d) {
-          const int k = c.t, pk = k ^ r;
-          const int p = k < pk ? k : pk, q = k < pk ? pk : k;
-          double cs;
-          cd w;
-          rotation(Ai[p * d + p].re, Ai[q * d + q].re, Ai[p * d + q], cs, w);
-          if (k < pk) w = cd{-w.re, w.im};  // J[pk][k]: -conj(w) if k is the lower index, else w
-          rc[k] = cs;
-          rw[k] = w;
-        }
         const cd a_c = Ai[i * d + pj], a_r = Ai[pi * d + j], a_x = Ai[pi * d + pj];
-        const cd v_c = Vi[i * d + pj];
-        __syncthreads();
+        const cd v_c{__shfl_xor(v.re, r, 64), __shfl_xor(v.im, r, 64)};
         const double cj = rc[j], ci = rc[i];
         const cd wj = rw[j], wi = rw[i];
-        const cd t0 = cadd(cscale(a, cj), cmul(a_c, wj));
-        const cd t1 = cadd(cscale(a_r, cj), cmul(a_x, wj));
-        a = cadd(cscale(t0, ci), cmulc(t1, wi));
+        if (c.t < 2 * d) {  // i = 0: diagonal pivots, i = 1: off-diagonal pivots; k = j
+          const int k = j, pk = k ^ rn, p = k < pk ? k : pk, q = k < pk ? pk : k;
+          const int x = i ? p : k, y = i ? q : k, px = x ^ r, py = y ^ r;
+          const cd e = rotate_elem(Ai[x * d + y], Ai[x * d + py], Ai[px * d + y], Ai[px * d + py], rc[y], rw[y], rc[x],
+                                   rw[x]);
+          const double d_pk = __shfl_xor(e.re, rn, 64);                     // A'[pk][pk] from lane pk
+          const cd a_pq{__shfl_down(e.re, d, 64), __shfl_down(e.im, d, 64)};  // A'[p][q] from lane d + k
+          if (i == 0) signed_rotation(k, pk, e.re, d_pk, a_pq, nc, nw);
+        }
+        a = rotate_elem(a, a_c, a_r, a_x, cj, wj, ci, wi);
         v = cadd(cscale(v, cj), cmul(v_c, wj));
         if (i == j) a.im = 0.0;
       }
@@ -438,7 +474,14 @@ struct Large {
   // noinline: inlined into the BFGS loop, hipcc hoists the ~100 loop-invariant LDS addresses of the
   // unrolled Pauli transforms out of that loop and, capped at 128 VGPRs by the 1024-thread workgroup,
   // spills them (1.4 KB of scratch per thread, reloaded inside every Cholesky / Jacobi step).
-  __device__ __attribute__((noinline)) static void nll_grad(const Ctx& c, double xt, double& f, double& gt) {
+  // Out of line the LDS base in Ctx arrives as a generic pointer and every access through it would be a
+  // flat_load / flat_store (all 224 of them were); the assumption tells the compiler where it points and
+  // they become ds_read / ds_write again.
+  __device__ __attribute__((noinline)) static void nll_grad(const Ctx& cin, double xt, double& f, double& gt) {
+    Ctx c = cin;
+#if defined(__HIP_DEVICE_COMPILE__)  // (the builtin has no host-side declaration)
+    __builtin_assume(__builtin_amdgcn_is_shared(c.sm));
+#endif
     double tr;
     QT_STAMP(11);
     const cd m = build_llh(c, xt, tr);

@@ -328,6 +328,9 @@ struct Large {
     rc[k] = cs;
     rw[k] = w;
   }
+  // (Tried on top: wavefront 0 doing nothing but the look-ahead, its rows carried by wavefront 1 as a second
+  //  element per lane -- 5 % slower at n = 5; the rounds are bound by the LDS queue right after each barrier,
+  //  scripts/jacobi_wave_timing.py, not by wavefront 0.)
   __device__ static cd psd_project(const Ctx& c, cd a, double eps) {
     const int i = c.i, j = c.j;
     // (buffers are picked by OFFSET from the LDS base: with an array of two pointers indexed at run time the
@@ -348,6 +351,9 @@ struct Large {
                       reinterpret_cast<cd*>(c.sm + oRot + d));
     }
     int which = 0, cur = 0;
+#ifdef QT_PHASE_TIMING  // per wavefront: clocks spent working / waiting at the round barrier (slots 19 / 31)
+    long long t_work = 0, t_wait = 0, t_last = (long long)__builtin_readcyclecounter();
+#endif
     for (int sweep = 0; sweep < 30; ++sweep) {
       const double off = bsum(c, i != j ? a.re * a.re + a.im * a.im : 0.0);
       QT_STAMP_VAL(20 + (sweep < 11 ? sweep : 11), (long long)(off / nrm * 1e30));
@@ -365,7 +371,18 @@ struct Large {
         which ^= 1;
         cur ^= 1;
         Ai[c.t] = a;
+#ifdef QT_PHASE_TIMING
+        const long long t_b0 = (long long)__builtin_readcyclecounter();
+#endif
         __syncthreads();
+#ifdef QT_PHASE_TIMING
+        {
+          const long long t_b1 = (long long)__builtin_readcyclecounter();
+          t_work += t_b0 - t_last;
+          t_wait += t_b1 - t_b0;
+          t_last = t_b1;
+        }
+#endif
         const int pj = j ^ r, pi = i ^ r;
         const cd a_c = Ai[i * d + pj], a_r = Ai[pi * d + j], a_x = Ai[pi * d + pj];
         const cd v_c{__shfl_xor(v.re, r, 64), __shfl_xor(v.im, r, 64)};
@@ -385,6 +402,8 @@ struct Large {
         if (i == j) a.im = 0.0;
       }
     }
+    QT_STAMP_VAL(19, t_work);
+    QT_STAMP_VAL(31, t_wait);
     double* lam = c.lam();
     Vi[c.e] = v;
     if (i == j) lam[i] = a.re;
@@ -552,7 +571,7 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_lin_large(PovmView pv, const 
                                                              int physical, double* __restrict__ rho,
                                                              double* __restrict__ bloch_out, int32_t* __restrict__ status) {
   using S = Large<NQ>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x;
   if (b >= B) return;
   typename S::Ctx c;
@@ -571,7 +590,7 @@ template <int NQ>
 __global__ void __launch_bounds__(Large<NQ>::NT) k_chol_param_large(PovmView pv, const double* __restrict__ rho, int B,
                                                                     double* __restrict__ x, int32_t* __restrict__ status) {
   using S = Large<NQ>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x;
   if (b >= B) return;
   typename S::Ctx c;
@@ -587,7 +606,7 @@ template <int NQ>
 __global__ void __launch_bounds__(Large<NQ>::NT) k_chol_unparam_large(PovmView pv, const double* __restrict__ x, int B,
                                                                       double* __restrict__ llh) {
   using S = Large<NQ>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x;
   if (b >= B) return;
   typename S::Ctx c;
@@ -606,7 +625,7 @@ template <int NQ>
 __global__ void __launch_bounds__(Large<NQ>::NT) k_born_large(PovmView pv, const double* __restrict__ bloch, int B,
                                                               double* __restrict__ p) {
   using S = Large<NQ>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x;
   if (b >= B) return;
   typename S::Ctx c;
@@ -635,7 +654,7 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_nll_large(PovmView pv, const 
                                                              const int64_t* __restrict__ counts, int B,
                                                              double* __restrict__ f, double* __restrict__ grad) {
   using S = Large<NQ>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x;
   if (b >= B) return;
   typename S::Ctx c;
@@ -656,7 +675,7 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
                                                              double* __restrict__ pairs) {
   using S = Large<NQ>;
   constexpr int D = S::D, d = S::d;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x;
   if (b >= B) return;
   typename S::Ctx c;

@@ -50,7 +50,12 @@ __device__ long long* g_qt_prof = nullptr;  // [waves][32]
 #define QT_STAMP_VAL(slot, val) do {} while (0)
 #endif
 
-struct cd {
+// 16-byte aligned: a complex element then moves with ONE ds_read_b128 / ds_write_b128 (4 LDS cycles per
+// wavefront read, conflict-free on consecutive elements).  With 8-byte alignment hipcc emits ds_read2_b64 /
+// ds_write2_b64, whose two 8-byte halves each stride 16 bytes across the lanes: a built-in 2-way bank
+// conflict, 16 cycles per read (measured on the n = 5 Jacobi rounds: 2700 -> see DESIGN 4.5).  Every cd
+// array in LDS starts at an even double offset (checked where the layouts are defined).
+struct alignas(16) cd {
   double re, im;
 };
 __device__ __forceinline__ cd cmul(cd a, cd b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
@@ -322,7 +327,7 @@ struct Small {
   }
   __host__ __device__ static int table_ints(int M, int R1) { return (fwd_ints(R1) + bwd_ints(R1) + M + 1) & ~1; }
   __host__ __device__ static int table_doubles(int M, int R1) {
-    return R1 > 0 ? table_ints(M, R1) / 2 + M : 0;  // index tables, then the row weights wrowR[M]
+    return R1 > 0 ? ((table_ints(M, R1) / 2 + M + 1) & ~1) : 0;  // index tables, then the row weights wrowR[M]; even
   }
   __host__ __device__ static size_t lds_bytes(int M, int R1 = 0) {
     return ((size_t)image_doubles(M) + table_doubles(M, R1) + (size_t)TPB * trial_doubles(M, R1)) * sizeof(double);
@@ -1104,7 +1109,7 @@ __global__ void __launch_bounds__(256) k_lin_batch(PovmView pv, const int64_t* _
                                                    double* __restrict__ rho, double* __restrict__ bloch_out,
                                                    int32_t* __restrict__ status) {
   using S = Small<NQ, ALDS>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   typename S::Ctx c;
   bool live;
   const int b = S::trial_index(B, &live);
@@ -1135,7 +1140,7 @@ template <int NQ>
 __global__ void __launch_bounds__(256) k_chol_param(PovmView pv, const double* __restrict__ rho, int B,
                                                     double* __restrict__ x, int32_t* __restrict__ status) {
   using S = Small<NQ, false>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
   bool live;
@@ -1155,7 +1160,7 @@ template <int NQ>
 __global__ void __launch_bounds__(256) k_chol_unparam(PovmView pv, const double* __restrict__ x, int B,
                                                       double* __restrict__ llh) {
   using S = Small<NQ, false>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
   bool live;
@@ -1176,7 +1181,7 @@ __global__ void __launch_bounds__(256) k_nll_batch(PovmView pv, const double* __
                                                    const int64_t* __restrict__ counts, int B, double* __restrict__ f,
                                                    double* __restrict__ grad) {
   using S = Small<NQ, ALDS>;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
   bool live;
@@ -1206,7 +1211,7 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
                                                    double* __restrict__ ws_f, int32_t* __restrict__ ws_active) {
   using S = Small<NQ, ALDS>;
   constexpr int D = S::D, G = S::G, d = S::d;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   typename S::Ctx c;
   bool live;
   const int b = S::trial_index(B, &live);
@@ -1393,7 +1398,7 @@ __global__ void __launch_bounds__(256) k_mle_bfgs(PovmView pv, const int64_t* __
   const int b = S::trial_index(B, &live);
   const bool mine = live && ws_active[b] != 0;
   if (!__syncthreads_or(mine)) return;  // nothing left to iterate in this workgroup
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
   const int bb = live ? b : B - 1;
@@ -1416,7 +1421,7 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
                                                    double* __restrict__ fun_out, int32_t* __restrict__ status_out) {
   using S = Small<NQ, ALDS>;
   constexpr int D = S::D, G = S::G, d = S::d;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   typename S::Ctx c;
   bool live;
   const int b = S::trial_index(B, &live);
@@ -1492,7 +1497,7 @@ __global__ void __launch_bounds__(256) k_mhmc_state(PovmView pv, const int64_t* 
                                                     double* __restrict__ chain, int32_t* __restrict__ accepted) {
   using S = Small<NQ, ALDS>;
   constexpr int D = S::D, G = S::G;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   typename S::Ctx c;
   S::make_ctx(c, smem, pv);
   bool live;

@@ -11,6 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "qt_ops.h"    // v4f64
+#include "qt_small.h"  // gsum
+
 namespace qt {
 
 struct ProcessState {
@@ -588,6 +591,127 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT, 2) k_mhmc_process(const int64_
       out[1] = xi;
     }
     if (tid == 0) accepted[(size_t)b * T_steps + t] = acc ? 1 : 0;
+  }
+}
+
+// ---- 'lifp' over a batch as a GEMM on the FP64 matrix cores (n = 2) -------------------------------------------
+// For many processes at once, Choi-vector = pinv . freq is [B x R] . [R x 2 NE] (freq real, pinv complex with
+// re / im interleaved: exactly the layout of pinvT).  k_lifp_batch reads the whole 2.4 MB operand from L2 for
+// every process (24 TB/s at B = 1024: the L2 is the limit); here a workgroup keeps a 16-column slice of it in
+// LDS ([R][16] doubles, 74 KB at R = 576) and its wavefronts take 16 processes at a time through
+// v_mfma_f64_16x16x4_f64, streaming their frequency rows as the A operand (64 k-values requested ahead).
+//
+// Step 1: counts [B][DC][M] -> frequencies [B][R = DC M], normalised per input state (process.py:285);
+// one wavefront per (process, input state) row.  F has 64 more entries than rows x M, set to zero here.
+__global__ void __launch_bounds__(256) k_lifp_freq(const int64_t* __restrict__ counts, int rows, int M,
+                                                   double* __restrict__ F) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x < 64) F[(size_t)rows * M + threadIdx.x] = 0.0;  // the 64 zeros k_lifp_gemm runs into
+  if (row >= rows) return;
+  const int64_t* c = counts + (size_t)row * M;
+  double part = 0.0;
+  for (int m = lane; m < M; m += 64) part += (double)c[m];
+  const double tot = gsum<64>(part);
+  for (int m = lane; m < M; m += 64) F[(size_t)row * M + m] = (double)c[m] / tot;
+}
+
+// Step 2: grid = (2 NE / 16 column slices, blocks of 64 processes); R % 16 == 0 (R = 16 M).  Operand layout of the MFMA
+// as in k_born_mfma (qt_ops.h): lane (r16, kq) supplies A[r16][kq] and B[kq][r16], and receives rows
+// kq + 4 r of column r16.  Column n = 2 v + part of the product is the re / im part of Choi-vector entry
+// v = col * DC + row (routines.py:59-61), i.e. of element (row, col): written straight to choi[b][row][col].
+template <int DC>
+__global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F, int B, int R, int Rp,
+                                                   const double* __restrict__ pinvT, double* __restrict__ choi) {
+  constexpr int NE = DC * DC, N = 2 * NE;
+  extern __shared__ double s_p[];  // [Rp][16] (rows R .. Rp-1 zero), then 4 x 256 doubles for the split-K sum
+  const int c0 = blockIdx.x * 16;
+  // (twelve loads in flight per thread: written as a plain copy loop, each iteration waits out an L2 round trip)
+  for (int e0 = threadIdx.x; e0 < Rp * 16; e0 += 12 * 512) {
+    double t[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int e = e0 + u * 512;
+      t[u] = e < R * 16 ? pinvT[(size_t)(e >> 4) * N + c0 + (e & 15)] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int e = e0 + u * 512;
+      if (e < Rp * 16) s_p[e] = t[u];
+    }
+  }
+  __syncthreads();
+  // 8 wavefronts = 4 groups of 16 processes x 2 halves of K: two wavefronts per tile double the number of
+  // independent MFMA chains per SIMD (a tile's MFMAs all accumulate into the same registers)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int grp = wave & 3, half = wave >> 2;
+  const int g = blockIdx.y * 4 + grp;
+  const int row = g * 16 + r16;
+  const int kh = ((Rp / 2 + 63) / 64) * 64;  // first half: [0, kh), second: [kh, Rp); both whole 64-chunks
+  const int kbeg = half ? kh : 0, kend = half ? Rp : kh;
+  // k-values of MFMA step u in lane group kq:  k0 + 8 (u / 2) + 2 kq + ((u ^ kq) & 1).  The A operand then comes
+  // in 16-byte pairs: the four lane groups of a row read one full 64-byte line per load (the plain
+  // k0 + 4 u + kq order makes every load 16 half-used lines of 8 bytes per lane), and the swapped order inside
+  // the pairs of the odd lane groups keeps the B-operand rows of lane groups {0, 1} and {2, 3} on opposite
+  // halves of the LDS banks (row pitch 128 bytes).  No bounds tests in the loop: the slice is zero-padded to
+  // Rp rows, and the A rows may run up to 63 values into the next row (finite frequencies; the buffer ends
+  // with 64 zeros), which meet those zeros.  Rows beyond B compute on row 0 and are not stored.
+  const double2* fr = reinterpret_cast<const double2*>(F + (size_t)(row < B ? row : 0) * R) + kq;
+  const bool swap = kq & 1;
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  double2 a[8], an[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = fr[(kbeg + 8 * j) / 2];
+  for (int k0 = kbeg; k0 < kend; k0 += 64) {
+    // next chunk's A operand, requested before this chunk's MFMAs (the last iteration re-reads the first chunk:
+    // a branch here would let the compiler sink the loads below the MFMA chain)
+    const int kn = k0 + 64 < kend ? k0 + 64 : kbeg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) an[j] = fr[(kn + 8 * j) / 2];
+    // all 16 B-operand reads of the chunk first (two base addresses, immediate offsets), then the MFMA chain
+    const double* b_first = s_p + (k0 + 2 * kq + (swap ? 1 : 0)) * 16 + r16;
+    const double* b_second = s_p + (k0 + 2 * kq + (swap ? 0 : 1)) * 16 + r16;
+    double b0[8], b1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      b0[j] = b_first[8 * j * 16];
+      b1[j] = b_second[8 * j * 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double lo = swap ? a[j].y : a[j].x, hi = swap ? a[j].x : a[j].y;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, b0[j], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, b1[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = an[j];
+  }
+  double* red = s_p + Rp * 16 + grp * 256;
+  if (half) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (!half) {
+    const int n = c0 + r16, v = n >> 1, part = n & 1;
+    const int er = v % DC, ec = v / DC;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = g * 16 + kq + 4 * r;
+      if (orow < B) choi[((size_t)orow * NE + er * DC + ec) * 2 + part] = acc[r] + red[r * 64 + lane];
+    }
+  }
+}
+
+// NaN check of element (0, 0), the one k_lifp_batch looks at
+__global__ void k_lifp_status(const double* __restrict__ choi, int B, int ne, int32_t* __restrict__ status,
+                              int32_t* __restrict__ zero_iters) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    const double x = choi[(size_t)b * ne * 2];
+    if (status) status[b] = (x == x) ? 0 : 4;
+    if (zero_iters) zero_iters[b] = 0;  // no projection ran
   }
 }
 

@@ -936,12 +936,36 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
   const size_t dyn = (size_t)D * M * sizeof(double);
   if (dyn > 32 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the process kernel");
-  if (D == 4)
+  const int R = D * M, Rp = (R + 63) / 64 * 64;
+  const size_t gemm_lds = ((size_t)Rp * 16 + 4 * 256) * sizeof(double);
+  if (D == 4) {
     hipLaunchKernelGGL(qt::k_lifp_batch<4>, dim3(B), dim3(qt::ProcWG<4>::NT), dyn, h->stream, dc, B, M,
                        (const double*)h->proc.pinvT, cptp, dchoi, dit, dst);
-  else
+  } else if (B >= 256 && gemm_lds <= 152 * 1024) {
+    // many processes: frequencies, then one FP64 MFMA GEMM over the batch, then (cptp) the projection kernel
+    constexpr int NE = 256;
+    HIPCHK(h->ws_x.ensure(((size_t)B * R + 64) * sizeof(double)));
+    double* F = h->ws_x.as<double>();
+    double* raw = dchoi;
+    if (cptp) {
+      HIPCHK(h->ws_g.ensure((size_t)B * NE * 2 * sizeof(double)));
+      raw = h->ws_g.as<double>();
+    }
+    hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 3) / 4), dim3(256), 0, h->stream, dc, B * D, M, F);
+    if (int r = allow_big_lds(qt::k_lifp_gemm<16>, gemm_lds)) return r;
+    const int row_blocks = (B + 63) / 64;  // 4 groups of 16 processes per workgroup (x 2 halves of K)
+    hipLaunchKernelGGL(qt::k_lifp_gemm<16>, dim3(2 * NE / 16, row_blocks), dim3(512), gemm_lds, h->stream, F, B, R, Rp,
+                       (const double*)h->proc.pinvT, raw);
+    if (cptp)
+      hipLaunchKernelGGL(qt::k_cptp_project<16>, dim3(B), dim3(qt::ProcWG<16>::NT), 0, h->stream, (const double*)raw, B, 0,
+                         1000, 1e-12, dchoi, dit);
+    if (dst || (!cptp && dit))
+      hipLaunchKernelGGL(qt::k_lifp_status, dim3((B + 255) / 256), dim3(256), 0, h->stream, (const double*)dchoi, B, NE, dst,
+                         cptp ? (int32_t*)nullptr : dit);
+  } else {
     hipLaunchKernelGGL(qt::k_lifp_batch<16>, dim3(B), dim3(qt::ProcWG<16>::NT), dyn, h->stream, dc, B, M,
                        (const double*)h->proc.pinvT, cptp, dchoi, dit, dst);
+  }
   if (int r = fetch_out(h, dchoi, choi, (size_t)B * D * D * 2, flags)) return r;
   if (int r = fetch_out(h, dit, iters, (size_t)B, flags)) return r;
   if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;

@@ -221,3 +221,34 @@ def test_routines_on_gpu(qp, oracle):
     with pytest.raises(np.linalg.LinAlgError):
         routines._matrix_to_real_tril_vec(np.diag([1.0, -1.0]).astype(complex))
     assert np.array_equal(np.asarray(qp.generate_pauli(2)), oracle.pauli_basis(2))
+
+
+def test_lifp_batched_gemm_path_matches_fused_kernel_and_oracle(qp, oracle):
+    """n = 2, B >= 256: frequencies + FP64 MFMA GEMM over the batch (+ projection kernel) against the one-process-
+    per-workgroup kernel the small batches use, and against the oracle on a few trials; a ragged batch size
+    (not a multiple of 16) exercises the row guards."""
+    np.random.seed(31)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.3, 2))
+    tmg.experiment(5000, "proj-set")
+    eng = tmg._engine()
+    base = tmg.results.reshape(16, -1)
+    nset = tmg.results.shape[1]
+    rng = np.random.default_rng(5)
+    b = 307
+    counts = rng.multinomial(5000, np.full(4, 0.25), size=(b, 16, nset)).astype(np.int64)
+    counts[0] = tmg.results  # one realistic trial
+    assert base.shape[1] == nset * 4
+    ins = oracle.input_states("proj4", 2)
+    a = oracle.measurement_matrix("proj-set", 2)
+    for cptp in (False, True):
+        big, it_big = eng.lifp(counts, cptp=cptp, return_iters=True)  # GEMM path
+        small = [eng.lifp(counts[lo:lo + 100], cptp=cptp, return_iters=True) for lo in range(0, b, 100)]  # fused kernel
+        ref = np.concatenate([s[0] for s in small])
+        it_ref = np.concatenate([s[1] for s in small])
+        assert np.abs(big - ref).max() < 1e-12
+        assert np.array_equal(it_big, it_ref)
+        for t in (0, 1, b - 1):
+            want = oracle.lifp_estimate(counts[t], a, ins)
+            if cptp:
+                want = oracle.cptp_projection(want, 2)
+            assert np.abs(big[t] - want).max() < 1e-9

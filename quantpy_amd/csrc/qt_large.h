@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "qt_jacobi_wg.h"
 #include "qt_linesearch.h"
 #include "qt_small.h"
 
@@ -300,124 +301,13 @@ struct Large {
     return r;
   }
 
-  // ---- a7: Jacobi eigenvalue clip (XOR order) ------------------------------------------------------
-  // One round = d/2 disjoint rotations; element (i, j) needs the rotation of its column pair (j, j ^ r)
-  // and of its row pair (i, i ^ r).  The d rotations of a round hang on 3 d/2 pivot elements only, so they
-  // are computed ONE ROUND AHEAD: while everybody applies round r, the first 2 d threads bring the
-  // pivots of round r + 1 up to date themselves (thread k < d the diagonal element (k, k), thread d + k
-  // the off-diagonal one of k's next pair; same arithmetic as the owners of those elements), turn them
-  // into cos / w and leave them in the other of two small LDS tables; the barrier of round r + 1 publishes
-  // them.  One barrier per round and nobody waits for a rotation: v9 computed them between two barriers
-  // with all other wavefronts idle (~2500 clk per round at d = 32); each wavefront computing all d
-  // rotations for itself was tried and is bound by the 4 x 16 copies of that arithmetic instead (slower).
-  // The A image alternates between two buffers (the Y overlay and the L region, which holds nothing live
-  // here: the factorisation that called us has failed); V never goes to LDS: V[i][j ^ r] is in lane l ^ r.
-  __device__ __forceinline__ static cd rotate_elem(cd a, cd a_c, cd a_r, cd a_x, double cj, cd wj, double ci, cd wi) {
-    // A'_ij = ci (a_ij cj + a_i,pj wj) + conj(wi) (a_pi,j cj + a_pi,pj wj)
-    const cd t0 = cadd(cscale(a, cj), cmul(a_c, wj));
-    const cd t1 = cadd(cscale(a_r, cj), cmul(a_x, wj));
-    return cadd(cscale(t0, ci), cmulc(t1, wi));
-  }
-  // rotation of index k in the round that pairs k with pk, already signed for k's side:
-  // J[pk][k] = -conj(w) if k is the lower index, else w
-  __device__ __forceinline__ static void signed_rotation(int k, int pk, double a_kk, double a_pkpk, cd a_pq, double* rc, cd* rw) {
-    double cs;
-    cd w;
-    rotation(k < pk ? a_kk : a_pkpk, k < pk ? a_pkpk : a_kk, a_pq, cs, w);
-    if (k < pk) w = cd{-w.re, w.im};
-    rc[k] = cs;
-    rw[k] = w;
-  }
-  // (Tried on top: wavefront 0 doing nothing but the look-ahead, its rows carried by wavefront 1 as a second
-  //  element per lane -- 5 % slower at n = 5; the rounds are bound by the LDS queue right after each barrier,
-  //  scripts/jacobi_wave_timing.py, not by wavefront 0.)
+  // ---- a7: Jacobi eigenvalue clip: qt_jacobi_wg.h.  The A image alternates between the Y overlay and the L region
+  // (which holds nothing live here: the factorisation that called us has failed), V goes to the X overlay.
   __device__ static cd psd_project(const Ctx& c, cd a, double eps) {
-    const int i = c.i, j = c.j;
-    // (buffers are picked by OFFSET from the LDS base: with an array of two pointers indexed at run time the
-    //  compiler loses the address space and emits flat_load / flat_store for every access in the loop)
-    const int img_off[2] = {(int)(c.Y() - c.sm), oL};
-    cd* img1 = reinterpret_cast<cd*>(c.sm + oL);
-    cd* Vi = c.Vimg();
-    cd v{i == j ? 1.0 : 0.0, 0.0};
-    if (i == j) a.im = 0.0;
-    const double nrm = bsum(c, a.re * a.re + a.im * a.im);
-    // (the rounds use the unpadded pitch d: their pivot reads A[p][q] over lanes j spread over the
-    //  banks through q = j ^ r, and padding the rows makes them collide instead)
-    img1[c.t] = a;
-    __syncthreads();
-    if (c.t < d) {  // rotations of the very first round, from the input itself
-      const int k = c.t, pk = k ^ 1, p = k < pk ? k : pk, q = k < pk ? pk : k;
-      signed_rotation(k, pk, img1[k * d + k].re, img1[pk * d + pk].re, img1[p * d + q], c.sm + oRot,
-                      reinterpret_cast<cd*>(c.sm + oRot + d));
-    }
-    int which = 0, cur = 0;
-#ifdef QT_PHASE_TIMING  // per wavefront: clocks spent working / waiting at the round barrier (slots 19 / 31)
-    long long t_work = 0, t_wait = 0, t_last = (long long)__builtin_readcyclecounter();
-#endif
-    for (int sweep = 0; sweep < 30; ++sweep) {
-      const double off = bsum(c, i != j ? a.re * a.re + a.im * a.im : 0.0);
-      QT_STAMP_VAL(20 + (sweep < 11 ? sweep : 11), (long long)(off / nrm * 1e30));
-      // off-diagonal norm <= 1e-13 of the matrix norm: by the Lipschitz bound of the clip the result moves by
-      // no more than that (~2e-14 here).  At d = 16, 32 most trials arrive at 1e-27 .. 1e-28 after their last
-      // useful sweep; a 1e-28 threshold sent them through one more (measured: profile build, slot 20+).
-      if (!(off > 1e-26 * nrm)) break;  // uniform: every thread holds the same sums
-      for (int r = 1; r < d; ++r) {
-        const int rn = r + 1 < d ? r + 1 : 1;  // the round after this one (round 1 of the next sweep)
-        cd* Ai = reinterpret_cast<cd*>(c.sm + (which ? img_off[1] : img_off[0]));
-        const double* rc = c.sm + oRot + (cur ? 3 * d : 0);  // cos [d], w [d] complex, twice
-        const cd* rw = reinterpret_cast<const cd*>(rc + d);
-        double* nc = c.sm + oRot + (cur ? 0 : 3 * d);
-        cd* nw = reinterpret_cast<cd*>(nc + d);
-        which ^= 1;
-        cur ^= 1;
-        Ai[c.t] = a;
-#ifdef QT_PHASE_TIMING
-        const long long t_b0 = (long long)__builtin_readcyclecounter();
-#endif
-        __syncthreads();
-#ifdef QT_PHASE_TIMING
-        {
-          const long long t_b1 = (long long)__builtin_readcyclecounter();
-          t_work += t_b0 - t_last;
-          t_wait += t_b1 - t_b0;
-          t_last = t_b1;
-        }
-#endif
-        const int pj = j ^ r, pi = i ^ r;
-        const cd a_c = Ai[i * d + pj], a_r = Ai[pi * d + j], a_x = Ai[pi * d + pj];
-        const cd v_c{__shfl_xor(v.re, r, 64), __shfl_xor(v.im, r, 64)};
-        const double cj = rc[j], ci = rc[i];
-        const cd wj = rw[j], wi = rw[i];
-        if (c.t < 2 * d) {  // i = 0: diagonal pivots, i = 1: off-diagonal pivots; k = j
-          const int k = j, pk = k ^ rn, p = k < pk ? k : pk, q = k < pk ? pk : k;
-          const int x = i ? p : k, y = i ? q : k, px = x ^ r, py = y ^ r;
-          const cd e = rotate_elem(Ai[x * d + y], Ai[x * d + py], Ai[px * d + y], Ai[px * d + py], rc[y], rw[y], rc[x],
-                                   rw[x]);
-          const double d_pk = __shfl_xor(e.re, rn, 64);                     // A'[pk][pk] from lane pk
-          const cd a_pq{__shfl_down(e.re, d, 64), __shfl_down(e.im, d, 64)};  // A'[p][q] from lane d + k
-          if (i == 0) signed_rotation(k, pk, e.re, d_pk, a_pq, nc, nw);
-        }
-        a = rotate_elem(a, a_c, a_r, a_x, cj, wj, ci, wi);
-        v = cadd(cscale(v, cj), cmul(v_c, wj));
-        if (i == j) a.im = 0.0;
-      }
-    }
-    QT_STAMP_VAL(19, t_work);
-    QT_STAMP_VAL(31, t_wait);
-    double* lam = c.lam();
-    Vi[c.e] = v;
-    if (i == j) lam[i] = a.re;
-    __syncthreads();
-    cd rr{0.0, 0.0};
-#pragma unroll 4  // fully unrolled, hipcc keeps all 2 d operands live for the imaginary part and spills them
-    for (int k = 0; k < d; ++k) {
-      const double lc = lam[k] > eps ? lam[k] : eps;
-      const cd p = cmulc(Vi[i * LD + k], Vi[j * LD + k]);
-      rr.re += lc * p.re;
-      rr.im += lc * p.im;
-    }
-    const double tr = bsum(c, i == j ? rr.re : 0.0);
-    return cd{rr.re / tr, rr.im / tr};
+    using J = JacobiWG<d, NT, true>;
+    static_assert(J::LDV == LD, "the eigenvector image uses the pitch of the other d x d images");
+    const typename J::Lds o{(int)(c.Y() - c.sm), oL, oRot, (int)(c.X() - c.sm), oLam, oRed};
+    return J::clip(c.t, a, eps, c.sm, o, true);
   }
 
   // ---- a8: Cholesky (image in the A overlay, factor in L) ------------------------------------------

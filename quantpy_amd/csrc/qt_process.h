@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "qt_jacobi_wg.h"
 #include "qt_ops.h"    // v4f64
 #include "qt_small.h"  // gsum
 
@@ -84,13 +85,22 @@ struct ProcWG {
   // reads of the Jacobi rounds and of the rebuild fall on two banks (8-way conflicts).
   static constexpr int LDC = DC + 1;
   static constexpr int NEP = DC * LDC;
+  // The CP step's eigensolver: DC = 16 uses the workgroup Jacobi of qt_jacobi_wg.h (one thread per element, one
+  // barrier per round) in its own LDS block `jac`; DC = 4 (16 active threads of one wavefront) keeps the small
+  // round-robin version below with the v* / r* / o* arrays.
+  static constexpr bool kWgJacobi = DC == 16;
+  using JW = JacobiWG<kWgJacobi ? DC : 16, kWgJacobi ? NE : 256, false>;
+  static constexpr int oJimg0 = 0, oJimg1 = oJimg0 + 2 * NE, oJrot = oJimg1 + 2 * NE, oJv = oJrot + 6 * DC,
+                       oJlam = oJv + 2 * DC * (DC + 1), oJred = oJlam + DC, kJacDoubles = oJred + 32;
+  static constexpr int NEV = kWgJacobi ? 2 : NEP;  // eigenvector images of the small version
   struct Sh {
     double are[NEP], aim[NEP];   // work matrix
     double tre[NEP], tim[NEP];   // column-rotated matrix
-    double vre[2][NEP], vim[2][NEP];  // eigenvectors, double buffered
+    double vre[2][NEV], vim[2][NEV];  // eigenvectors, double buffered (DC = 4)
     double rc[DC], ore[DC], oim[DC];
     double red[16];
     double rre[DQ * DQ], rim[DQ * DQ];  // reduced (input-space) matrix of the TP step
+    alignas(16) double jac[kWgJacobi ? kJacDoubles : 2];
   };
 
   __device__ __forceinline__ static int partner(int i, int r) {
@@ -162,6 +172,14 @@ struct ProcWG {
         im = ai;
         return;
       }
+    }
+    if constexpr (kWgJacobi) {
+      const typename JW::Lds o{oJimg0, oJimg1, oJrot, oJv, oJlam, oJred};
+      const cd out = JW::clip(threadIdx.x, cd{ar, ai}, eps, sh.jac, o, false);
+      __syncthreads();  // the caller goes on to overwrite the a* / t* images; nothing of `jac` is read after this
+      re = out.re;
+      im = out.im;
+      return;
     }
     int cur = 0;
     if (act) {

@@ -1289,9 +1289,19 @@ __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx
   ls.start(fk, old_old, gsum<G>(gk * pk), &stp);
   const int eval_cap = (max_iter + 2) * 130;  // hard stop: every wave leaves the loop
 
+#ifdef QT_PHASE_TIMING  // slots 21 / 22: clocks in this loop / inside its nll_grad calls; 23 / 24: iterations, evaluations
+  long long t_nll = 0;
+  const long long t_loop0 = (long long)__builtin_readcyclecounter();
+#endif
   while (__any(active)) {  // per wave: the waves of a workgroup do not synchronise here
     double ft, gt;
+#ifdef QT_PHASE_TIMING
+    const long long t_e0 = (long long)__builtin_readcyclecounter();
+#endif
     S::nll_grad(c, xk + stp * pk, ft, gt);  // executed by the whole wave; finished trials idle through it
+#ifdef QT_PHASE_TIMING
+    t_nll += (long long)__builtin_readcyclecounter() - t_e0;
+#endif
     if (active && ++nfev > eval_cap) {
       status = 2;
       active = false;
@@ -1342,6 +1352,8 @@ __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx
           ubuf[D + c.l] = sk;
           wave_sync();
           const double cc = rhok * rhok * yhy + rhok;
+          // (regrouped as H_lk += a_l s_k + b_l u_k with (u_k, s_k) read as one 16-byte pair: two FMAs per element
+          //  instead of five operations, and measured 6 % SLOWER per iteration -- scripts/bfgs_phase_timing.py)
 #pragma unroll
           for (int k = 0; k < D; ++k)
             H[k] += -rhok * (u * ubuf[D + k] + sk * ubuf[k]) + cc * sk * ubuf[D + k];
@@ -1363,6 +1375,12 @@ __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx
       }
     }
   }
+#ifdef QT_PHASE_TIMING
+  QT_STAMP_VAL(21, (long long)__builtin_readcyclecounter() - t_loop0);
+  QT_STAMP_VAL(22, t_nll);
+  QT_STAMP_VAL(23, (long long)kiter);
+  QT_STAMP_VAL(24, (long long)nfev);
+#endif
   if (status == 0) {
     const double gn = gmax<G>(fabs(gk));
     const double xn = gmax<G>(fabs(xk));

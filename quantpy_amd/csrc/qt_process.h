@@ -663,10 +663,12 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   const int grp = wave & 3, half = wave >> 2;
-  const int g = blockIdx.y * 4 + grp;
-  const int row = g * 16 + r16;
   const int kh = ((Rp / 2 + 63) / 64) * 64;  // first half: [0, kh), second: [kh, Rp); both whole 64-chunks
   const int kbeg = half ? kh : 0, kend = half ? Rp : kh;
+  const int nblocks = (B + 63) / 64;
+  for (int blk = blockIdx.y; blk < nblocks; blk += gridDim.y) {  // uniform per workgroup
+  const int g = blk * 4 + grp;
+  const int row = g * 16 + r16;
   // k-values of MFMA step u in lane group kq:  k0 + 8 (u / 2) + 2 kq + ((u ^ kq) & 1).  The A operand then comes
   // in 16-byte pairs: the four lane groups of a row read one full 64-byte line per load (the plain
   // k0 + 4 u + kq order makes every load 16 half-used lines of 8 bytes per lane), and the swapped order inside
@@ -719,6 +721,8 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
       const int orow = g * 16 + kq + 4 * r;
       if (orow < B) choi[((size_t)orow * NE + er * DC + ec) * 2 + part] = acc[r] + red[r * 64 + lane];
     }
+  }
+  __syncthreads();  // `red` is reused by the next block of processes
   }
 }
 

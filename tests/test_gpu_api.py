@@ -252,3 +252,9 @@ def test_lifp_batched_gemm_path_matches_fused_kernel_and_oracle(qp, oracle):
             if cptp:
                 want = oracle.cptp_projection(want, 2)
             assert np.abs(big[t] - want).max() < 1e-9
+    # enough blocks of 64 processes for a workgroup to take several of them with one staged operand slice
+    b2 = 2100
+    counts2 = rng.multinomial(5000, np.full(4, 0.25), size=(b2, 16, nset)).astype(np.int64)
+    big = eng.lifp(counts2, cptp=False)
+    ref = np.concatenate([eng.lifp(counts2[lo:lo + 200], cptp=False) for lo in range(0, b2, 200)])
+    assert np.abs(big - ref).max() < 1e-12

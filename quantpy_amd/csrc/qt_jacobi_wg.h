@@ -12,7 +12,7 @@ namespace qt {
 
 template <int d, int NT, bool STAMPS>
 struct JacobiWG {
-  static_assert(NT == d * d && NT % 64 == 0, "one thread per matrix element");
+  static_assert(NT == d * d && NT % 64 == 0 && (d & (d - 1)) == 0, "one thread per matrix element, d a power of two");
   static constexpr int LDV = d + 1;  // pitch of the eigenvector image (conflict-free column reads in the rebuild)
   static constexpr int NW = NT / 64;
   // LDS regions, as offsets in doubles from the (16-byte aligned) base `sm`; all even:
@@ -113,8 +113,9 @@ struct JacobiWG {
           t_last = t_b1;
         }
 #endif
-        const int pj = j ^ r, pi = i ^ r;
-        const cd a_c = Ai[i * d + pj], a_r = Ai[pi * d + j], a_x = Ai[pi * d + pj];
+        // partner elements (i, j ^ r), (i ^ r, j), (i ^ r, j ^ r): with t = i * d + j and d a power of two these
+        // are t ^ r, t ^ (r d), t ^ (r d + r) -- one XOR each instead of rebuilding the index from (i, j)
+        const cd a_c = Ai[t ^ r], a_r = Ai[t ^ (r * d)], a_x = Ai[t ^ (r * d + r)];
         const cd v_c{__shfl_xor(v.re, r, 64), __shfl_xor(v.im, r, 64)};
         const double cj = rc[j], ci = rc[i];
         const cd wj = rw[j], wi = rw[i];

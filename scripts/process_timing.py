@@ -39,3 +39,18 @@ for cptp in (False, True):
     ms = eng.timer_end() / 5
     print(f"lifp B={B} cptp={cptp}: {ms:8.3f} ms / launch  {B / ms * 1e3:12.1f} processes/s   Dykstra iterations "
           f"{it.cpu().numpy()[:8]}", flush=True)
+
+# the projection kernel by itself on the raw (unprojected) Choi matrices: Dykstra / TP step only / CP step only
+from quantpy_amd import _capi  # noqa: E402
+
+raw = torch.empty_like(choi)
+eng.lifp_dev(cd, raw, cptp=False)
+for mode, name in ((0, "Dykstra CPTP"), (1, "TP projection only"), (2, "CP projection only")):
+    args = (eng._h, raw.data_ptr(), B, mode, 1000, 1e-12, choi.data_ptr(), it.data_ptr(), _capi.QT_DEVICE_PTR)
+    eng._chk(eng.lib.qt_cptp_project_batch(*args))
+    eng.sync()
+    eng.timer_begin()
+    for _ in range(5):
+        eng._chk(eng.lib.qt_cptp_project_batch(*args))
+    ms = eng.timer_end() / 5
+    print(f"qt_cptp_project_batch B={B} {name:20s}: {ms:8.3f} ms / launch", flush=True)

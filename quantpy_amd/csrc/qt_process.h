@@ -180,7 +180,7 @@ struct ProcWG {
       re = out.re;
       im = out.im;
       return;
-    }
+    } else {  // DC = 4: the small round-robin version
     int cur = 0;
     if (act) {
       sh.are[e] = ar;
@@ -279,6 +279,7 @@ struct ProcWG {
       im = ri;
     }
     __syncthreads();
+    }  // DC = 4
   }
 
   // TP projection (process.py:259-265) of the matrix whose element (i, j) this thread holds:

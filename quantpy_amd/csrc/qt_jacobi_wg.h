@@ -61,7 +61,10 @@ struct JacobiWG {
   // (Tried on top: wavefront 0 doing nothing but the look-ahead, its rows carried by wavefront 1 as a second
   //  element per lane -- 5 % slower at n = 5; the rounds are bound by the LDS queue right after each barrier,
   //  scripts/jacobi_wave_timing.py, not by wavefront 0.)
-  __device__ static cd clip(const int t, cd a, const double eps, double* sm, const Lds o, const bool normalise) {
+  // warm: the eigenvector image still holds the (unitary) V of an earlier call on a nearby matrix -- the sweeps then
+  // start from V^dagger A V, which is already close to diagonal, and continue to accumulate into that V.
+  __device__ static cd clip(const int t, cd a, const double eps, double* sm, const Lds o, const bool normalise,
+                            const bool warm = false) {
     const int i = t / d, j = t % d;
     double* red = sm + o.red;
     // (buffers are picked by OFFSET from the LDS base: with an array of two pointers indexed at run time the
@@ -75,6 +78,27 @@ struct JacobiWG {
     //  banks through q = j ^ r, and padding the rows makes them collide instead)
     img1[t] = a;
     __syncthreads();
+    if (warm) {  // uniform
+      cd* img0 = reinterpret_cast<cd*>(sm + o.img0);
+      cd b{0.0, 0.0};  // (A V)_ij
+#pragma unroll 4
+      for (int k = 0; k < d; ++k) b = cadd(b, cmul(img1[i * d + k], Vi[k * LDV + j]));
+      img0[t] = b;
+      v = Vi[i * LDV + j];
+      __syncthreads();
+      cd w{0.0, 0.0};  // (V^dagger A V)_ij = sum_k conj(V_ki) (A V)_kj
+#pragma unroll 4
+      for (int k = 0; k < d; ++k) {
+        const cd vk = Vi[k * LDV + i], bk = img0[k * d + j];
+        w.re = fma(vk.re, bk.re, fma(vk.im, bk.im, w.re));
+        w.im = fma(vk.re, bk.im, fma(-vk.im, bk.re, w.im));
+      }
+      a = w;
+      if (i == j) a.im = 0.0;
+      __syncthreads();  // every read of the old img1 / V image is done
+      img1[t] = a;
+      __syncthreads();
+    }
     if (t < d) {  // rotations of the very first round, from the input itself
       const int k = t, pk = k ^ 1, p = k < pk ? k : pk, q = k < pk ? pk : k;
       signed_rotation(k, pk, img1[k * d + k].re, img1[pk * d + pk].re, img1[p * d + q], sm + o.rot,

@@ -113,7 +113,10 @@ struct ProcWG {
 
   // CP projection (process.py:270-277): eigh on the lower triangle, clip at eps, rebuild.
   // (re, im) = this thread's element (i, j); returns the projected element.
-  __device__ static void cp_project(Sh& sh, bool act, int i, int j, double& re, double& im, double eps) {
+  // warm (DC = 16): in / out -- set when this call's eigensolve may start from the eigenvectors a previous call left
+  // in `jac`, and set by a call that ran the eigensolver (see JacobiWG::clip)
+  __device__ static void cp_project(Sh& sh, bool act, int i, int j, double& re, double& im, double eps,
+                                    bool* warm = nullptr) {
     const int e = i * LDC + j;
     // Hermitian completion from the lower triangle, like LAPACK's zheevd with uplo = 'L'
     if (act) {
@@ -175,7 +178,8 @@ struct ProcWG {
     }
     if constexpr (kWgJacobi) {
       const typename JW::Lds o{oJimg0, oJimg1, oJrot, oJv, oJlam, oJred};
-      const cd out = JW::clip(threadIdx.x, cd{ar, ai}, eps, sh.jac, o, false);
+      const cd out = JW::clip(threadIdx.x, cd{ar, ai}, eps, sh.jac, o, false, warm && *warm);
+      if (warm) *warm = true;
       __syncthreads();  // the caller goes on to overwrite the a* / t* images; nothing of `jac` is read after this
       re = out.re;
       im = out.im;
@@ -316,6 +320,9 @@ struct ProcWG {
   __device__ static int dykstra(Sh& sh, bool act, int i, int j, double& xr, double& xi, int n_iter, double tol) {
     double pr = 0.0, pim = 0.0, qr = 0.0, qi = 0.0, yr = 0.0, yi = 0.0;
     int it = 0;
+    // successive CP steps see nearly the same matrix: from the second eigensolve on, start from the eigenvectors
+    // of the previous one (2-3 sweeps instead of ~7); every Dykstra run starts cold, so rounding in V cannot pile up
+    bool warm = false;
     for (; it < n_iter; ++it) {
       double tr_ = xr + pr, ti_ = xi + pim;
       tp_project(sh, act, i, j, tr_, ti_);
@@ -323,7 +330,7 @@ struct ProcWG {
       yr += ydr;
       yi += ydi;
       double cr = yr + qr, ci = yi + qi;
-      cp_project(sh, act, i, j, cr, ci, 1e-12);
+      cp_project(sh, act, i, j, cr, ci, 1e-12, &warm);
       const double xdr = cr - xr, xdi = ci - xi;
       xr += xdr;
       xi += xdi;

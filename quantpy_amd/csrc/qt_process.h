@@ -150,23 +150,27 @@ struct ProcWG {
       __syncthreads();
       double wr = ar, wi = ai;
       int pd = 1;
+      // the trailing block alternates between the t* and the a* images (the a* pair is free again: the completed
+      // element is in registers), so a step needs one barrier; unrolled: the image of a step is a constant
+#pragma unroll
       for (int k = 0; k < DC; ++k) {
-        const double piv = sh.tre[k * LDC + k];
+        const double* cre = (k & 1) ? sh.are : sh.tre;
+        const double* cim = (k & 1) ? sh.aim : sh.tim;
+        double* nre = (k & 1) ? sh.tre : sh.are;
+        double* nim = (k & 1) ? sh.tim : sh.aim;
+        const double piv = cre[k * LDC + k];
         if (!(piv > eps)) {
           pd = 0;  // uniform: every thread reads the same pivot
           break;
         }
         if (act && i > k && j > k) {
-          const double ikr = sh.tre[i * LDC + k], iki = sh.tim[i * LDC + k];
-          const double jkr = sh.tre[j * LDC + k], jki = sh.tim[j * LDC + k];
+          const double ikr = cre[i * LDC + k], iki = cim[i * LDC + k];
+          const double jkr = cre[j * LDC + k], jki = cim[j * LDC + k];
           const double inv = 1.0 / piv;
           wr -= (ikr * jkr + iki * jki) * inv;  // a_ik conj(a_jk) / a_kk
           wi -= (iki * jkr - ikr * jki) * inv;
-        }
-        __syncthreads();
-        if (act && i > k && j > k) {
-          sh.tre[e] = wr;
-          sh.tim[e] = wi;
+          nre[e] = wr;
+          nim[e] = wi;
         }
         __syncthreads();
       }

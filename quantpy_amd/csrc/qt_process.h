@@ -632,17 +632,19 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT, 2) k_mhmc_process(const int64_
 // v_mfma_f64_16x16x4_f64, streaming their frequency rows as the A operand (64 k-values requested ahead).
 //
 // Step 1: counts [B][DC][M] -> frequencies [B][R = DC M], normalised per input state (process.py:285);
-// one wavefront per (process, input state) row.  F has 64 more entries than rows x M, set to zero here.
+// 16 lanes per (process, input state) row.  F has 64 more entries than rows x M, set to zero here.
 __global__ void __launch_bounds__(256) k_lifp_freq(const int64_t* __restrict__ counts, int rows, int M,
                                                    double* __restrict__ F) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // 16 lanes per row (M = 36 at C3: three loads per lane, all in flight), 16 rows per workgroup
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   if (blockIdx.x == 0 && threadIdx.x < 64) F[(size_t)rows * M + threadIdx.x] = 0.0;  // the 64 zeros k_lifp_gemm runs into
-  if (row >= rows) return;
-  const int64_t* c = counts + (size_t)row * M;
+  const bool live = row < rows;
+  const int64_t* c = counts + (size_t)(live ? row : 0) * M;
   double part = 0.0;
-  for (int m = lane; m < M; m += 64) part += (double)c[m];
-  const double tot = gsum<64>(part);
-  for (int m = lane; m < M; m += 64) F[(size_t)row * M + m] = (double)c[m] / tot;
+  for (int m = l; m < M; m += 16) part += (double)c[m];
+  const double tot = gsum<16>(part);  // sums of integers: exact in any order
+  if (!live) return;
+  for (int m = l; m < M; m += 16) F[(size_t)row * M + m] = (double)c[m] / tot;
 }
 
 // Step 2: grid = (2 NE / 16 column slices, blocks of 64 processes); R % 16 == 0 (R = 16 M).  Operand layout of the MFMA
@@ -651,7 +653,8 @@ __global__ void __launch_bounds__(256) k_lifp_freq(const int64_t* __restrict__ c
 // v = col * DC + row (routines.py:59-61), i.e. of element (row, col): written straight to choi[b][row][col].
 template <int DC>
 __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F, int B, int R, int Rp,
-                                                   const double* __restrict__ pinvT, double* __restrict__ choi) {
+                                                   const double* __restrict__ pinvT, double* __restrict__ choi,
+                                                   int32_t* __restrict__ status, int32_t* __restrict__ zero_iters) {
   constexpr int NE = DC * DC, N = 2 * NE;
   extern __shared__ double s_p[];  // [Rp][16] (rows R .. Rp-1 zero), then 4 x 256 doubles for the split-K sum
   const int c0 = blockIdx.x * 16;
@@ -731,21 +734,17 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int orow = g * 16 + kq + 4 * r;
-      if (orow < B) choi[((size_t)orow * NE + er * DC + ec) * 2 + part] = acc[r] + red[r * 64 + lane];
+      if (orow < B) {
+        const double x = acc[r] + red[r * 64 + lane];
+        choi[((size_t)orow * NE + er * DC + ec) * 2 + part] = x;
+        if (n == 0) {  // Re C[0][0], the element k_lifp_batch tests; no projection follows when these are set
+          if (status) status[orow] = (x == x) ? 0 : 4;
+          if (zero_iters) zero_iters[orow] = 0;
+        }
+      }
     }
   }
   __syncthreads();  // `red` is reused by the next block of processes
-  }
-}
-
-// NaN check of element (0, 0), the one k_lifp_batch looks at
-__global__ void k_lifp_status(const double* __restrict__ choi, int B, int ne, int32_t* __restrict__ status,
-                              int32_t* __restrict__ zero_iters) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) {
-    const double x = choi[(size_t)b * ne * 2];
-    if (status) status[b] = (x == x) ? 0 : 4;
-    if (zero_iters) zero_iters[b] = 0;  // no projection ran
   }
 }
 
@@ -753,7 +752,8 @@ __global__ void k_lifp_status(const double* __restrict__ choi, int B, int ne, in
 template <int DC>
 __global__ void __launch_bounds__(ProcWG<DC>::NT, 4) k_cptp_project(const double* __restrict__ in, int B, int mode,
                                                                 int n_iter, double tol, double* __restrict__ out,
-                                                                int32_t* __restrict__ iters) {
+                                                                int32_t* __restrict__ iters,
+                                                                int32_t* __restrict__ status = nullptr) {
   using W = ProcWG<DC>;
   __shared__ typename W::Sh sh;
   const int b = blockIdx.x;
@@ -774,7 +774,10 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT, 4) k_cptp_project(const double
     out[((size_t)b * W::NE + tid) * 2] = xr;
     out[((size_t)b * W::NE + tid) * 2 + 1] = xi;
   }
-  if (tid == 0 && iters) iters[b] = it;
+  if (tid == 0) {
+    if (iters) iters[b] = it;
+    if (status) status[b] = (xr == xr) ? 0 : 4;
+  }
 }
 
 }  // namespace qt

@@ -951,7 +951,7 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
       HIPCHK(h->ws_g.ensure((size_t)B * NE * 2 * sizeof(double)));
       raw = h->ws_g.as<double>();
     }
-    hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 3) / 4), dim3(256), 0, h->stream, dc, B * D, M, F);
+    hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 15) / 16), dim3(256), 0, h->stream, dc, B * D, M, F);
     if (int r = allow_big_lds(qt::k_lifp_gemm<16>, gemm_lds)) return r;
     // 4 groups of 16 processes per workgroup pass (x 2 halves of K).  A workgroup keeps its operand slice for up
     // to 4 passes once there are enough blocks to fill the chip anyway (measured: B = 1024 best with 1-2 passes,
@@ -960,13 +960,10 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
     const int passes = nblocks >= 64 ? 4 : (nblocks >= 32 ? 2 : 1);
     const int row_blocks = (nblocks + passes - 1) / passes;
     hipLaunchKernelGGL(qt::k_lifp_gemm<16>, dim3(2 * NE / 16, row_blocks), dim3(512), gemm_lds, h->stream, F, B, R, Rp,
-                       (const double*)h->proc.pinvT, raw);
+                       (const double*)h->proc.pinvT, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
     if (cptp)
       hipLaunchKernelGGL(qt::k_cptp_project<16>, dim3(B), dim3(qt::ProcWG<16>::NT), 0, h->stream, (const double*)raw, B, 0,
-                         1000, 1e-12, dchoi, dit);
-    if (dst || (!cptp && dit))
-      hipLaunchKernelGGL(qt::k_lifp_status, dim3((B + 255) / 256), dim3(256), 0, h->stream, (const double*)dchoi, B, NE, dst,
-                         cptp ? (int32_t*)nullptr : dit);
+                         1000, 1e-12, dchoi, dit, dst);
   } else {
     hipLaunchKernelGGL(qt::k_lifp_batch<16>, dim3(B), dim3(qt::ProcWG<16>::NT), dyn, h->stream, dc, B, M,
                        (const double*)h->proc.pinvT, cptp, dchoi, dit, dst);

@@ -63,7 +63,7 @@ __global__ void k_transpose_c(const double* __restrict__ in, int R, int C, doubl
 
 template <int NT>
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v = gsum<64>(v);  // DPP: 8 vector instructions instead of 12 ds_bpermute round trips
   constexpr int NW = (NT + 63) / 64;
   if (NW == 1) return v;
   __syncthreads();
@@ -73,6 +73,28 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 #pragma unroll
   for (int w = 0; w < NW; ++w) s += scratch[w];
   return s;
+}
+
+// K sums at once (same order of additions per sum as block_sum): one barrier pair for all of them
+template <int NT, int K>
+__device__ __forceinline__ void block_sums(double (&v)[K], double* scratch /* [K][NT / 64] */) {
+  constexpr int NW = (NT + 63) / 64;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = gsum<64>(v[k]);
+  if (NW == 1) return;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) scratch[k * NW + (threadIdx.x >> 6)] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += scratch[k * NW + w];
+    v[k] = s;
+  }
 }
 
 template <int DC>
@@ -99,6 +121,7 @@ struct ProcWG {
     double vre[2][NEV], vim[2][NEV];  // eigenvectors, double buffered (DC = 4)
     double rc[DC], ore[DC], oim[DC];
     double red[16];
+    double red6[6 * ((NT + 63) / 64)];
     double rre[DQ * DQ], rim[DQ * DQ];  // reduced (input-space) matrix of the TP step
     alignas(16) double jac[kWgJacobi ? kJacDoubles : 2];
   };
@@ -338,21 +361,19 @@ struct ProcWG {
       const double xdr = cr - xr, xdi = ci - xi;
       xr += xdr;
       xi += xdi;
-      // 2 (|sum conj(y_diff) q| + |sum conj(x_diff) p|)
-      const double s1r = block_sum<NT>(act ? ydr * qr + ydi * qi : 0.0, sh.red);
-      const double s1i = block_sum<NT>(act ? ydr * qi - ydi * qr : 0.0, sh.red);
-      const double s2r = block_sum<NT>(act ? xdr * pr + xdi * pim : 0.0, sh.red);
-      const double s2i = block_sum<NT>(act ? xdr * pim - xdi * pr : 0.0, sh.red);
-      double crit = 2.0 * (hypot(s1r, s1i) + hypot(s2r, s2i));
+      // 2 (|sum conj(y_diff) q| + |sum conj(x_diff) p|) + |p_diff|^2 + |q_diff|^2: the six sums share one barrier pair
       const double pdr = xr - yr, pdi = xi - yi;
+      const double qdr = yr - xr, qdi = yi - xi;
+      double six[6] = {act ? ydr * qr + ydi * qi : 0.0,   act ? ydr * qi - ydi * qr : 0.0,
+                       act ? xdr * pr + xdi * pim : 0.0,  act ? xdr * pim - xdi * pr : 0.0,
+                       act ? pdr * pdr + pdi * pdi : 0.0, act ? qdr * qdr + qdi * qdi : 0.0};
+      block_sums<NT, 6>(six, sh.red6);
+      double crit = 2.0 * (hypot(six[0], six[1]) + hypot(six[2], six[3]));
       pr += pdr;
       pim += pdi;
-      const double qdr = yr - xr, qdi = yi - xi;
       qr += qdr;
       qi += qdi;
-      const double np2 = block_sum<NT>(act ? pdr * pdr + pdi * pdi : 0.0, sh.red);
-      const double nq2 = block_sum<NT>(act ? qdr * qdr + qdi * qdi : 0.0, sh.red);
-      crit += np2 + nq2;
+      crit += six[4] + six[5];
       if (crit < tol) {
         ++it;
         break;

@@ -653,19 +653,27 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT, 2) k_mhmc_process(const int64_
 // v_mfma_f64_16x16x4_f64, streaming their frequency rows as the A operand (64 k-values requested ahead).
 //
 // Step 1: counts [B][DC][M] -> frequencies [B][R = DC M], normalised per input state (process.py:285);
-// 16 lanes per (process, input state) row.  F has 64 more entries than rows x M, set to zero here.
-__global__ void __launch_bounds__(256) k_lifp_freq(const int64_t* __restrict__ counts, int rows, int M,
+// 16 lanes per (process, input state) row.
+__global__ void __launch_bounds__(256) k_lifp_freq(const int64_t* __restrict__ counts, int rows, int M, int DC, int Rp,
                                                    double* __restrict__ F) {
-  // 16 lanes per row (M = 36 at C3: three loads per lane, all in flight), 16 rows per workgroup
+  // 16 lanes per row (M = 36 at C3: three loads per lane, all in flight), 16 rows per workgroup.
+  // F is [B][Rp]: a process's R = DC M frequencies, then zeros up to the pitch Rp (a multiple of 64), so that
+  // k_lifp_gemm never reads one process's numbers into another's product (a NaN frequency -- an input state without
+  // counts -- must stay that process's own); 192 zeros follow the last process for its look-ahead loads.
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
-  if (blockIdx.x == 0 && threadIdx.x < 64) F[(size_t)rows * M + threadIdx.x] = 0.0;  // the 64 zeros k_lifp_gemm runs into
+  const int nproc = rows / DC, R = DC * M;
+  if (blockIdx.x == 0 && threadIdx.x < 192) F[(size_t)nproc * Rp + threadIdx.x] = 0.0;
   const bool live = row < rows;
   const int64_t* c = counts + (size_t)(live ? row : 0) * M;
   double part = 0.0;
   for (int m = l; m < M; m += 16) part += (double)c[m];
   const double tot = gsum<16>(part);  // sums of integers: exact in any order
   if (!live) return;
-  for (int m = l; m < M; m += 16) F[(size_t)row * M + m] = (double)c[m] / tot;
+  const int b = row / DC, st = row - b * DC;
+  double* f = F + (size_t)b * Rp;
+  for (int m = l; m < M; m += 16) f[st * M + m] = (double)c[m] / tot;
+  if (st == DC - 1)
+    for (int k = R + l; k < Rp; k += 16) f[k] = 0.0;
 }
 
 // Step 2: grid = (2 NE / 16 column slices, blocks of 64 processes); R % 16 == 0 (R = 16 M).  Operand layout of the MFMA
@@ -710,9 +718,9 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
   // k0 + 4 u + kq order makes every load 16 half-used lines of 8 bytes per lane), and the swapped order inside
   // the pairs of the odd lane groups keeps the B-operand rows of lane groups {0, 1} and {2, 3} on opposite
   // halves of the LDS banks (row pitch 128 bytes).  No bounds tests in the loop: the slice is zero-padded to
-  // Rp rows, and the A rows may run up to 63 values into the next row (finite frequencies; the buffer ends
-  // with 64 zeros), which meet those zeros.  Rows beyond B compute on row 0 and are not stored.
-  const double2* fr = reinterpret_cast<const double2*>(F + (size_t)(row < B ? row : 0) * R) + kq;
+  // Rp rows and so is every row of F (pitch Rp); the look-ahead of a row's last chunk reads the start of the next
+  // row (or the 192 zeros behind the last one) and is not used.  Rows beyond B compute on row 0 and are not stored.
+  const double2* fr = reinterpret_cast<const double2*>(F + (size_t)(row < B ? row : 0) * Rp) + kq;
   const bool swap = kq & 1;
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   double2 a[8], an[8];

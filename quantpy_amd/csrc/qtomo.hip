@@ -944,14 +944,14 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
   } else if (B >= 256 && gemm_lds <= 152 * 1024) {
     // many processes: frequencies, then one FP64 MFMA GEMM over the batch, then (cptp) the projection kernel
     constexpr int NE = 256;
-    HIPCHK(h->ws_x.ensure(((size_t)B * R + 64) * sizeof(double)));
+    HIPCHK(h->ws_x.ensure(((size_t)B * Rp + 192) * sizeof(double)));  // [B][Rp] + the zeros k_lifp_freq appends
     double* F = h->ws_x.as<double>();
     double* raw = dchoi;
     if (cptp) {
       HIPCHK(h->ws_g.ensure((size_t)B * NE * 2 * sizeof(double)));
       raw = h->ws_g.as<double>();
     }
-    hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 15) / 16), dim3(256), 0, h->stream, dc, B * D, M, F);
+    hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 15) / 16), dim3(256), 0, h->stream, dc, B * D, M, D, Rp, F);
     if (int r = allow_big_lds(qt::k_lifp_gemm<16>, gemm_lds)) return r;
     // 4 groups of 16 processes per workgroup pass (x 2 halves of K).  A workgroup keeps its operand slice for up
     // to 4 passes once there are enough blocks to fill the chip anyway (measured: B = 1024 best with 1-2 passes,

@@ -258,3 +258,27 @@ def test_lifp_batched_gemm_path_matches_fused_kernel_and_oracle(qp, oracle):
     big = eng.lifp(counts2, cptp=False)
     ref = np.concatenate([eng.lifp(counts2[lo:lo + 200], cptp=False) for lo in range(0, b2, 200)])
     assert np.abs(big - ref).max() < 1e-12
+
+
+def test_lifp_batched_ragged_povm_and_nan_isolation(qp):
+    """The batched path with a POVM whose row count R = 16 M is not a multiple of the GEMM's 64-wide K chunks
+    (five-outcome one-qubit POVM -> M = 25, R = 400, padded pitch 448), and with one process that has an input
+    state without counts: its own Choi matrix is NaN (as counts / 0 in the reference), its neighbours are not."""
+    sic = qp.generate_measurement_matrix("sic", 1)[0]  # (4, 4) Bloch rows
+    five = np.vstack([sic[:1] / 2, sic[:1] / 2, sic[1:]])  # first outcome split in two: still a complete POVM
+    np.random.seed(41)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.2, 2))
+    tmg.experiment(4000, five)
+    assert tmg.results.shape == (16, 1, 25)
+    eng = tmg._engine()
+    rng = np.random.default_rng(9)
+    b = 300
+    counts = rng.multinomial(4000, np.full(25, 0.04), size=(b, 16, 1)).astype(np.int64)
+    counts[0] = tmg.results
+    counts[137, 5] = 0  # process 137, input state 5: no counts at all
+    big = eng.lifp(counts, cptp=False)
+    ref = np.concatenate([eng.lifp(counts[lo:lo + 100], cptp=False) for lo in range(0, b, 100)])
+    assert np.isnan(big[137]).all() and np.isnan(ref[137]).all()
+    keep = np.arange(b) != 137
+    assert np.isfinite(big[keep]).all()
+    assert np.abs(big[keep] - ref[keep]).max() < 1e-12

@@ -1,7 +1,7 @@
 // Workgroup Jacobi eigenvalue clip  U max(lambda, eps) U^dagger  of a d x d Hermitian matrix held one element
 // per thread (d = 16, 32: 256 / 1024 threads, thread t = i * d + j).  Shared by the n = 4, 5 state kernels
-// (qt_large.h: a7, state.py:267-273) and the CP step of the n = 2 process kernels (qt_process.h: process.py:259-265).
-// Test infrastructure hooks (QT_STAMP*) only in the profile build and only when STAMPS is set.
+// (qt_large.h: a7, state.py:267-273) and the CP step of the n = 2 process kernels (qt_process.h: a15,
+// process.py:267-278).  Profiling stamps (QT_STAMP*) only in the profile build and only when STAMPS is set.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -177,7 +177,6 @@ struct JacobiWG {
     const double tr = wsum(red, i == j ? rr.re : 0.0);
     return cd{rr.re / tr, rr.im / tr};
   }
-
 };
 
 }  // namespace qt

@@ -258,6 +258,106 @@ __global__ void __launch_bounds__(1024) k_gauss_jordan(int n, double* __restrict
   }
 }
 
+// The same elimination for large n (the 256 x 256 complex Gram matrix of 2-qubit process tomography), spread over
+// the chip: one workgroup cannot keep 256 x 512 complex elements moving (12.5 ms: 48 us per pivot step, every
+// element through L2 by 1024 threads).  Per pivot step two launches on the handle's stream -- k_gj_pivot (one
+// workgroup: pivot search with the same rule, row swap, pivot row scaled) and k_gj_eliminate (one workgroup per
+// row) -- preceded by k_gj_identity.  Same arithmetic per element as k_gauss_jordan, so the same inverse.
+template <int CPLX>
+__global__ void k_gj_identity(int n, double* __restrict__ aug, int* __restrict__ info) {
+  constexpr int W = CPLX ? 2 : 1;
+  const int n2 = 2 * n;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
+    const int r = e / n, c = e % n;
+    aug[((size_t)r * n2 + n + c) * W] = (r == c) ? 1.0 : 0.0;
+    if (CPLX) aug[((size_t)r * n2 + n + c) * W + 1] = 0.0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *info = 0;
+}
+
+template <int CPLX>
+__global__ void __launch_bounds__(1024) k_gj_pivot(int n, double* __restrict__ aug, int k, int* __restrict__ info) {
+  constexpr int W = CPLX ? 2 : 1;
+  __shared__ double s_val[1024];
+  __shared__ int s_idx[1024];
+  __shared__ double s_piv[2];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n2 = 2 * n;
+  double best = -1.0;  // max |a_ik| over i >= k  (LAPACK izamax: |re| + |im| for complex), lowest row on ties
+  int bi = k;
+  for (int i = k + tid; i < n; i += nt) {
+    const double* p = aug + ((size_t)i * n2 + k) * W;
+    const double v = CPLX ? fabs(p[0]) + fabs(p[W - 1]) : fabs(p[0]);
+    if (v > best) {
+      best = v;
+      bi = i;
+    }
+  }
+  s_val[tid] = best;
+  s_idx[tid] = bi;
+  __syncthreads();
+  for (int s = nt / 2; s > 0; s >>= 1) {
+    if (tid < s) {
+      const double o = s_val[tid + s];
+      const int oi = s_idx[tid + s];
+      if (o > s_val[tid] || (o == s_val[tid] && oi < s_idx[tid])) {
+        s_val[tid] = o;
+        s_idx[tid] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  const int pr = s_idx[0];
+  if (tid == 0 && !(s_val[0] > 0.0) && *info == 0) *info = k + 1;
+  if (tid == 0) {
+    s_piv[0] = aug[((size_t)pr * n2 + k) * W];
+    if (CPLX) s_piv[1] = aug[((size_t)pr * n2 + k) * W + 1];
+  }
+  __syncthreads();
+  const double pr_ = s_piv[0], pi_ = CPLX ? s_piv[1] : 0.0;
+  const double den = pr_ * pr_ + pi_ * pi_;
+  for (int c = tid; c < n2; c += nt) {  // rows k and pr change places; the new row k is divided by the pivot
+    double* pk = aug + ((size_t)k * n2 + c) * W;
+    double* pp = aug + ((size_t)pr * n2 + c) * W;
+    const double kr = pk[0], ki = CPLX ? pk[W - 1] : 0.0;
+    const double xr = pp[0], xi = CPLX ? pp[W - 1] : 0.0;
+    if (pr != k) {
+      pp[0] = kr;
+      if (CPLX) pp[W - 1] = ki;
+    }
+    if (CPLX) {
+      pk[0] = (xr * pr_ + xi * pi_) / den;
+      pk[W - 1] = (xi * pr_ - xr * pi_) / den;
+    } else {
+      pk[0] = xr / pr_;
+    }
+  }
+}
+
+template <int CPLX>
+__global__ void __launch_bounds__(256) k_gj_eliminate(int n, double* __restrict__ aug, int k) {
+  constexpr int W = CPLX ? 2 : 1;
+  const int i = blockIdx.x, n2 = 2 * n;
+  if (i == k) return;
+  double* row = aug + (size_t)i * n2 * W;
+  const double* rk = aug + (size_t)k * n2 * W;
+  const double fr = row[(size_t)k * W], fi = CPLX ? row[(size_t)k * W + 1] : 0.0;
+  __syncthreads();  // every thread holds the factor before column k is cleared
+  for (int c = k + 1 + threadIdx.x; c < n2; c += blockDim.x) {  // columns < k of the left half are already e_j
+    if (CPLX) {
+      const double rr = rk[c * W], ri = rk[c * W + 1];
+      row[c * W] -= fr * rr - fi * ri;
+      row[c * W + 1] -= fr * ri + fi * rr;
+    } else {
+      row[c] -= fr * rk[c];
+    }
+  }
+  if (threadIdx.x == 0) {
+    row[(size_t)k * W] = 0.0;
+    if (CPLX) row[(size_t)k * W + 1] = 0.0;
+  }
+}
+
 // ---- a4: state.py:109-110  p[b][m] = clip(d * sum_k A[m][k] bloch[b][k], 0, 1) ---------------
 // 256 rows m per block, TB trials per block pass; the Bloch tile is staged in LDS and each A
 // element (read once, coalesced over m from the [D][M] layout) feeds TB accumulators.

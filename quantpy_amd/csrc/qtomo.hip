@@ -223,6 +223,22 @@ int need_product(qt_handle_t* h, bool need_uniform) {
     }                                                                                                       \
   } while (0)
 
+// In-place inverse of the n x n matrix in the left half of aug [n][2n]: one workgroup up to n = 127, the
+// chip-wide variant (qt_ops.h) beyond -- the 256 x 256 complex Gram matrix of 2-qubit process tomography takes
+// 12.5 ms in one workgroup and 1.8 ms as 2 x 256 small launches.
+template <int CPLX>
+void launch_gauss_jordan(qt_handle_t* h, int n, double* aug, int* info) {
+  if (n < 128) {
+    hipLaunchKernelGGL(qt::k_gauss_jordan<CPLX>, dim3(1), dim3(1024), 0, h->stream, n, aug, info);
+    return;
+  }
+  hipLaunchKernelGGL(qt::k_gj_identity<CPLX>, dim3(grid_for((size_t)n * n)), dim3(256), 0, h->stream, n, aug, info);
+  for (int k = 0; k < n; ++k) {
+    hipLaunchKernelGGL(qt::k_gj_pivot<CPLX>, dim3(1), dim3(1024), 0, h->stream, n, aug, k, info);
+    hipLaunchKernelGGL(qt::k_gj_eliminate<CPLX>, dim3(n), dim3(256), 0, h->stream, n, aug, k);
+  }
+}
+
 int need_povm(qt_handle_t* h) {
   if (!h->povm_set) return fail(QT_ERR_STATE, "qt_set_povm has not been called on this handle");
   return 0;
@@ -366,7 +382,7 @@ static int compute_dense_pinv(qt_handle_t* h) {
   double *dP = h->Pinv.as<double>(), *dPT = h->PinvT.as<double>(), *aug = h->aug.as<double>();
   dim3 gg((D + 15) / 16, (D + 15) / 16);
   hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(64), 0, h->stream, D, D, M, dAw, D, 1, dAw, D, 0, aug, 2 * D);
-  hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, D, aug, h->info.as<int>());
+  launch_gauss_jordan<0>(h, D, aug, h->info.as<int>());
   dim3 gp((M + 15) / 16, (D + 15) / 16);
   hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(64), 0, h->stream, D, M, D, aug + D, 2 * D, 0, dAwT, M, 0, dP, M);
   hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for((size_t)M * D)), dim3(256), 0, h->stream, dP, D, M, dPT);
@@ -850,12 +866,12 @@ int qt_left_inverse(qt_handle_t* h, const double* A, int rows, int cols, int is_
   dim3 gg((cols + 15) / 16, (cols + 15) / 16), gp((rows + 15) / 16, (cols + 15) / 16);
   if (is_complex) {
     hipLaunchKernelGGL(qt::k_gemm<1>, gg, dim3(64), 0, h->stream, cols, cols, rows, dA, cols, 1, dA, cols, 0, g, 2 * cols);
-    hipLaunchKernelGGL(qt::k_gauss_jordan<1>, dim3(1), dim3(1024), 0, h->stream, cols, g, h->info.as<int>());
+    launch_gauss_jordan<1>(h, cols, g, h->info.as<int>());
     hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(64), 0, h->stream, cols, rows, cols, g + (size_t)cols * 2, 2 * cols, 0, dA,
                        cols, 1, dout, rows);
   } else {
     hipLaunchKernelGGL(qt::k_gemm<0>, gg, dim3(64), 0, h->stream, cols, cols, rows, dA, cols, 1, dA, cols, 0, g, 2 * cols);
-    hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, cols, g, h->info.as<int>());
+    launch_gauss_jordan<0>(h, cols, g, h->info.as<int>());
     hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(64), 0, h->stream, cols, rows, cols, g + cols, 2 * cols, 0, dA, cols, 1,
                        dout, rows);
   }
@@ -897,7 +913,7 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
   const int c2 = (int)C2, rr = (int)R;
   dim3 gg((c2 + 15) / 16, (c2 + 15) / 16), gp((rr + 15) / 16, (c2 + 15) / 16);
   hipLaunchKernelGGL(qt::k_gemm<1>, gg, dim3(64), 0, h->stream, c2, c2, rr, lifp, c2, 1, lifp, c2, 0, aug, 2 * c2);
-  hipLaunchKernelGGL(qt::k_gauss_jordan<1>, dim3(1), dim3(1024), 0, h->stream, c2, aug, h->info.as<int>());
+  launch_gauss_jordan<1>(h, c2, aug, h->info.as<int>());
   hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(64), 0, h->stream, c2, rr, c2, aug + (size_t)c2 * 2, 2 * c2, 0, lifp, c2, 1,
                      pinv, rr);
   hipLaunchKernelGGL(qt::k_transpose_c, dim3(grid_for(R * C2)), dim3(256), 0, h->stream, pinv, c2, rr, pinvT);

@@ -214,6 +214,13 @@ def test_routines_on_gpu(qp, oracle):
     assert np.abs(routines._left_inv(a) - oracle.left_inv(a)).max() < 1e-12
     c = a[:, :5] + 1j * rng.standard_normal((30, 5))
     assert np.abs(routines._left_inv(c) - oracle.left_inv(c)).max() < 1e-12  # plain transpose, complex
+    # >= 128 columns: the Gauss-Jordan inverse runs chip-wide (two small launches per pivot step)
+    big = rng.standard_normal((400, 150))
+    assert np.abs(routines._left_inv(big) - oracle.left_inv(big)).max() < 1e-10
+    bigc = big[:, :130] + 1j * rng.standard_normal((400, 130))
+    assert np.abs(routines._left_inv(bigc) - oracle.left_inv(bigc)).max() < 1e-10
+    with pytest.raises(Exception):  # rank deficient: reported, not returned
+        routines._left_inv(np.hstack([big[:, :140], big[:, :1]]))
     rho = ginibre(rng, 4)
     x = routines._matrix_to_real_tril_vec(rho)
     assert np.abs(x - oracle.matrix_to_tril_vec(rho)).max() < 1e-14

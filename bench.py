@@ -7,15 +7,25 @@ One "step" = one pass of the hot path over one batch: qt_mle_batch on B = 1000 i
 3-qubit trials per GPU ('proj-set' POVM, 1e5 shots per setting, Ginibre state of
 np.random.default_rng(1234); counts drawn on the host from np.random.seed(7) in the
 reference's call order -- SURVEY.md section 8d).  Counts are resident in HBM before the timed
-region.  N > 1 (torchrun, one rank per GPU): each rank reconstructs its own 1000 trials
-(weak scaling, no data-path collective); afterwards the 2000-resample bootstrap CI of
-configs[3] is run strong-scaled with one RCCL all-gather and reported under "bootstrap_ci".
+region.
+
+N > 1: one rank per GPU over RCCL.  Either the driver starts the ranks (torchrun: WORLD_SIZE is
+set) or `python bench.py --gpus N` starts them itself as a CHILD `python -m torch.distributed.run`
+before anything in this process has touched the GPU.  Each rank reconstructs its own 1000 trials
+(weak scaling, no data-path collective); the group size is asserted equal to --gpus and reported as
+"rccl_ranks".  After the headline the sharded legs run on every rank:
+  "configs4_weak"     5-qubit MLE (configs[4]), 256 trials per rank, weak-scaled;
+  "bootstrap_ci"      the 2000-resample bootstrap CI of configs[3], strong-scaled, ONE all-gather;
+  "bootstrap_ci_n5"   the same for 5 qubits (2000 resamples), strong-scaled;
+  "bootstrap_ci_large" 262 144 resamples at n = 3 (a size where sharding matters), strong-scaled.
 
 Rank 0 prints ONE JSON line (contract in the task statement) that also carries
-  "roofline":     the dominant kernel (k_mle_batch<3>) against the HBM roofline, from HIP-event
-                  timing of back-to-back launches on the engine's stream;
+  "roofline":     the dominant kernel against the HBM roofline, from HIP-event timing of
+                  back-to-back launches on the stream the kernel runs on;
   "cpu_baseline": the CPU oracle (oracle/quantpy_oracle.py: scipy BFGS + forward differences,
-                  i.e. the reference's algorithm) timed on one host core on a bounded sample.
+                  i.e. the reference's algorithm) timed on one host core on a bounded sample;
+  "iterating":    the regime in which BFGS really iterates (configs[1] counts from the fully mixed
+                  start; a rank-1 state from the 'lin' start), with parity against the oracle.
 """
 import argparse
 import json
@@ -38,12 +48,17 @@ def ginibre(rng, d):
     return rho / np.trace(rho)
 
 
-def _cpu_worker(job):
-    """One host core of the all-cores CPU baseline: the oracle (the reference's algorithm) on its slice."""
-    counts, n_trials = job
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import quantpy_oracle as qo
 
+    return qo
+
+
+def _cpu_worker(job):
+    """One host core of the all-cores CPU baseline: the oracle (the reference's algorithm) on its slice."""
+    counts, n_trials = job
+    qo = _oracle()
     try:
         from threadpoolctl import threadpool_limits
 
@@ -63,9 +78,7 @@ def cpu_all_cores(shots, per_core):
     import concurrent.futures as cf
     import multiprocessing as mp
 
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import quantpy_oracle as qo
-
+    qo = _oracle()
     # the CPU share that goes with one GPU of the node is 16 cores, whatever the affinity mask shows
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     povm = qo.measurement_matrix("proj-set", 3)
@@ -81,6 +94,40 @@ def cpu_all_cores(shots, per_core):
             "sample": f"{per_core} reconstructions on each of {cores} worker processes (one per core of the box's CPU share, capped at 16), slowest worker {max(busy):.1f} s, {wall:.1f} s with process start-up"}
 
 
+def launch_ranks(args):
+    """Run `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a child process, pass its
+    output through (rank 0 prints the one JSON line) and return its exit code."""
+    import socket
+    import subprocess
+
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def vector_resamples(povm, bloch, shots, n, seed):
+    """`n` multinomial count tensors (n, S, K) for one state, drawn setting by setting in vectorised calls of a
+    seeded Generator.  Input generation for the LARGE bootstrap legs only: valid resamples, but not the reference's
+    stream order (that order -- one legacy-RNG call per setting per resample -- is kept wherever counts are
+    compared with the reference: the headline batch, configs[3]'s 2000 resamples, the tests)."""
+    d = int(round(np.sqrt(povm.shape[-1])))
+    p = np.clip(np.einsum("ijk,k->ij", np.asarray(povm), bloch) * d, 0, 1)
+    p = p / p.sum(-1, keepdims=True)
+    rng = np.random.default_rng(seed)
+    out = np.empty((n,) + p.shape, dtype=np.int64)
+    for s in range(p.shape[0]):
+        out[:, s, :] = rng.multinomial(int(shots[s]), p[s], size=n)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,32 +140,61 @@ def main():
     ap.add_argument("--cpu-per-core", type=int, default=1500,
                     help="reconstructions per worker in the all-cores CPU baseline; 0 = skip it")
     ap.add_argument("--bootstrap-points", type=int, default=2000)
+    ap.add_argument("--bootstrap-large", type=int, default=262144, help="resamples of the large n = 3 bootstrap leg; 0 = off")
     ap.add_argument("--saturation-batch", type=int, default=65536, help="extra (untimed-contract) measurement; 0 = off")
     ap.add_argument("--pipelined-steps", type=int, default=0,
                     help="extra: this many steps alternated over two streams (off by default so that a rocprofv3 pass over the "
                          "default command sees single-stream launches only)")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / configs[4] side measurements")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / configs[4] / iterating side measurements")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself")
+    ap.add_argument("--launch-check", action="store_true", help="form the process group (gloo, CPU) and exit: launcher test")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves.  This parent has imported neither torch nor
+        # libqtomo (nothing here has touched the GPU); the ranks are CHILD processes, never an exec.
+        sys.exit(launch_ranks(args))
+    force_dist = os.environ.get("QT_BENCH_FORCE_DIST") == "1"  # 1-rank group: rehearsal of the RCCL path
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a mislabelled number",
+              file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
     cpu_all = None
-    if (rank == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline
-            and args.cpu_per_core > 0):
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_per_core > 0:
         try:
             cpu_all = cpu_all_cores(args.shots, args.cpu_per_core)
         except Exception as exc:  # the single-core figure below is the contract; this one is a supplement
             cpu_all = {"error": f"{type(exc).__name__}: {exc}"}
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
 
     import torch
     import torch.distributed as dist
 
+    if args.launch_check:
+        # CPU-only check of the launcher path (tests/test_host_logic.py): the ranks this process started (or the
+        # driver's torchrun) form a group of --gpus members; nothing here touches a GPU.
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        probe = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(probe)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "rank_sum": int(probe.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+
     dev_index = 0 if args.share_gpu0 else local_rank
+    if not args.share_gpu0 and world > torch.cuda.device_count():
+        print(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s) (use --share-gpu0 for a rehearsal)",
+              file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(dev_index)
-    use_dist = world > 1 or os.environ.get("QT_BENCH_FORCE_DIST") == "1"  # (1-rank group: rehearsal of the RCCL path)
+    use_dist = world > 1 or force_dist
+    rccl_ranks = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -128,10 +204,28 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        # prove that the collective library sees every rank: sum of (rank + 1) over the group
+        probe = torch.tensor([float(rank + 1)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        assert int(probe.item()) == world * (world + 1) // 2, probe
+        rccl_ranks = dist.get_world_size() if args.backend == "nccl" else 0
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     import quantpy_amd as qp
+    from quantpy_amd import distributed as qd
     from quantpy_amd.tomography.state import simulate_counts
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     n, d, B = 3, 8, args.batch
     rho_true = ginibre(np.random.default_rng(1234), d)
@@ -147,7 +241,8 @@ def main():
     all_counts = np.stack([simulate_counts(povm, bloch, shots) for _ in range(B * world)])
     counts = all_counts[rank * B:(rank + 1) * B]
 
-    eng = qp.get_engine(n, device=dev_index)
+    eng = qp.get_engine(n)  # this process's GPU (torch.cuda.current_device())
+    assert eng.device == dev_index, (eng.device, dev_index)
     eng.set_povm(povm, shots)
     counts_d = torch.from_numpy(np.ascontiguousarray(counts)).cuda()
     rho_d = torch.empty((B, d, d), dtype=torch.complex128, device="cuda")
@@ -157,10 +252,6 @@ def main():
 
     def step():
         eng.mle_dev(counts_d, rho_d, init="lin", max_iter=100, tol=1e-3, nit=nit_d, nfev=nfev_d, status=st_d)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -177,11 +268,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    assert torch.cuda.current_device() == dev_index  # engine calls leave the thread's device alone
 
     nit = nit_d.cpu().numpy()
     nfev = nfev_d.cpu().numpy()
@@ -201,12 +289,16 @@ def main():
     flops_eval = 4 * M * D + 16 * D * d + 2 * 8 * d**3
     flops_trial = 2 * M * D + 8 * D * d + 60 * 8 * d**3 + float(nfev.mean()) * flops_eval
     fp64_tflops = flops_trial * B / (kernel_ms * 1e-3) / 1e12
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
-    if B == 1000 and os.path.exists(pmc_file):  # HBM bytes per launch from the committed PMC passes
-        with open(pmc_file) as fh:
-            pmc = json.load(fh)
-        traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    traffic, traffic_src, executed = None, None, None
+    for cand in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+        pmc_file = os.path.join(ROOT, "profiles", cand)
+        if B == 1000 and os.path.exists(pmc_file):  # HBM bytes per launch from the committed PMC passes
+            with open(pmc_file) as fh:
+                pmc = json.load(fh)
+            traffic = pmc["traffic_bytes_per_launch"]
+            traffic_src = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            executed = pmc.get("executed")
+            break
     # qt_mle_batch runs the single-launch kernel while the batch fits one wave per SIMD (<= 1024 waves)
     dominant_kernel = ("qt::k_mle_fused<3,false>" if B <= 1024 else
                        "qt::k_mle_start<3,false> (+ qt::k_mle_bfgs<3,false> for the trials that iterate)")
@@ -217,10 +309,21 @@ def main():
         "bytes_per_launch": int(launch_bytes), "kernel_ms": round(kernel_ms, 5),
         "note": "n=3 working set is LDS/register resident: the step is bound by single-wave instruction issue "
                 "(one wave per SIMD at B=1000), not by HBM (SURVEY 8d, DESIGN.md 4.1); dense-equivalent FP64 rate beside it",
+        "executed_instruction_utilisation": executed,
         "fp64_dense_equivalent": {"achieved": round(fp64_tflops, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(fp64_tflops / FP64_PEAK_TFLOPS, 6),
-                                  "note": "flops of the dense (unfactorised) algorithm for the same work / FP64 vector peak"},
+                                  "note": "flops of the dense (unfactorised) algorithm for the same work / FP64 vector peak "
+                                          "-- NOT utilisation: the factorised kernel executes ~8x fewer"},
     }
+
+    def timed(fn, reps, engine=None):
+        e = engine or eng
+        fn()
+        e.sync()
+        e.timer_begin()
+        for _ in range(reps):
+            fn()
+        return e.timer_end() / reps
 
     # ---- the same step at a batch that fills the chip (occupancy hides the single-wave latency) ----
     sat = None
@@ -229,44 +332,76 @@ def main():
         reps = (Bs + B - 1) // B
         big = torch.from_numpy(np.ascontiguousarray(np.concatenate([counts] * reps)[:Bs])).cuda()
         rho_s = torch.empty((Bs, d, d), dtype=torch.complex128, device="cuda")
-        eng.mle_dev(big, rho_s)
-        eng.sync()
-        eng.timer_begin()
-        for _ in range(10):
-            eng.mle_dev(big, rho_s)
-        ms = eng.timer_end() / 10
+        ms = timed(lambda: eng.mle_dev(big, rho_s), 10)
         sat = {"batch": Bs, "ms_per_step": round(ms, 4), "value": round(Bs / ms * 1e3, 1), "unit": "reconstructions/s",
                "hbm_GBps": round(bytes_per_recon * Bs / (ms * 1e-3) / 1e9, 2),
                "fp64_TFLOPs_dense_equivalent": round(flops_trial * Bs / (ms * 1e-3) / 1e12, 3)}
         del big, rho_s
 
     # ---- the same steps issued alternately on two handles (two HIP streams) ----------------------
-    # A 1000-trial launch puts one trial-wave on each SIMD and lasts as long as its slowest trial (the
-    # 25 % that need the eigenvalue clip); with a second stream the next batch starts on the SIMDs that
-    # are already free.  Reported beside `value`, which stays the single-stream figure.
     piped = None
     if rank == 0 and args.pipelined_steps > 0:
         from quantpy_amd.engine import Engine
 
-        eng2 = Engine(n, dev_index)
-        eng2.set_povm(povm, shots)
-        engs = (eng, eng2)
+        engs = (Engine(n, dev_index, stream="own"), Engine(n, dev_index, stream="own"))
+        for e in engs:
+            e.set_povm(povm, shots)
         outs = (rho_d, torch.empty_like(rho_d))
+        torch.cuda.synchronize()
         for k in range(20):
             engs[k & 1].mle_dev(counts_d, outs[k & 1])
-        eng.sync()
-        eng2.sync()
+        for e in engs:
+            e.sync()
         tp = time.perf_counter()
         for k in range(args.pipelined_steps):
             engs[k & 1].mle_dev(counts_d, outs[k & 1])
-        eng.sync()
-        eng2.sync()
+        for e in engs:
+            e.sync()
         dt = time.perf_counter() - tp
         same = bool(torch.equal(outs[0], outs[1]))
         piped = {"steps": args.pipelined_steps, "streams": 2, "ms_per_step": round(dt / args.pipelined_steps * 1e3, 5),
                  "value": round(B * args.pipelined_steps / dt, 1), "unit": "reconstructions/s",
                  "outputs_identical_across_streams": same}
-        eng2.close()
+        for e in engs:
+            e.close()
+
+    # ---- the regime in which BFGS iterates (state.py:204-215 is THE hot loop of SURVEY 3.3) -------
+    iterating = None
+    if rank == 0 and not args.no_other_configs:
+        qo = _oracle()
+        iterating = {}
+        povm_np = np.asarray(povm)
+        prng = np.random.default_rng(77)
+        psi = prng.standard_normal(d) + 1j * prng.standard_normal(d)
+        psi /= np.linalg.norm(psi)
+        pure = qp.Qobj(np.outer(psi, psi.conj()))
+        np.random.seed(9)
+        pure_counts = np.stack([simulate_counts(povm, pure.bloch, shots) for _ in range(B)])
+        for name, cts, init in (("configs[1] counts, init='mixed'", counts, "mixed"),
+                                ("rank-1 state, 1e5 shots, init='lin'", pure_counts, "lin")):
+            c_d = torch.from_numpy(np.ascontiguousarray(cts)).cuda()
+            r_d = torch.empty((len(cts), d, d), dtype=torch.complex128, device="cuda")
+            ni_d = torch.zeros(len(cts), dtype=torch.int32, device="cuda")
+            nf_d = torch.zeros(len(cts), dtype=torch.int32, device="cuda")
+            s_d = torch.zeros(len(cts), dtype=torch.int32, device="cuda")
+            ms = timed(lambda: eng.mle_dev(c_d, r_d, init=init, nit=ni_d, nfev=nf_d, status=s_d), 20)
+            r_h, ni_h = r_d.cpu().numpy(), ni_d.cpu().numpy()
+            same_nit, worst = 0, 0.0
+            for i in range(64):
+                ref, ri = qo.mle_estimate(cts[i], povm_np, init=init, return_info=True, solver="port")
+                same_nit += int(ri["nit"] == ni_h[i])
+                worst = max(worst, abs(qo.infidelity(ref, r_h[i])))
+            Bs = 65536
+            big = c_d.repeat((Bs + len(cts) - 1) // len(cts), 1, 1)[:Bs].contiguous()
+            rb = torch.empty((Bs, d, d), dtype=torch.complex128, device="cuda")
+            ms_big = timed(lambda: eng.mle_dev(big, rb, init=init), 3)
+            iterating[name] = {
+                "batch": len(cts), "ms_per_step": round(ms, 4), "value": round(len(cts) / ms * 1e3, 1),
+                "unit": "reconstructions/s", "mean_nit": float(ni_h.mean()), "max_nit": int(ni_h.max()),
+                "mean_nfev": float(nf_d.float().mean().item()), "nonzero_status": int((s_d != 0).sum().item()),
+                "parity_vs_oracle_64_trials": {"identical_nit": same_nit, "max_infidelity": float(f"{worst:.3e}")},
+                "saturated": {"batch": Bs, "ms_per_step": round(ms_big, 3), "value": round(Bs / ms_big * 1e3, 1)}}
+            del big, rb
 
     # ---- the other single-GPU configurations of BASELINE.json, one short measurement each ---------
     others = None
@@ -281,84 +416,127 @@ def main():
         pc = torch.from_numpy(np.ascontiguousarray(np.stack([ptm.results] * pb))).cuda()
         pout = torch.empty((pb, 16, 16), dtype=torch.complex128, device="cuda")
         for cptp in (False, True):
-            peng.lifp_dev(pc, pout, cptp=cptp)
-            peng.sync()
-            peng.timer_begin()
-            for _ in range(5):
-                peng.lifp_dev(pc, pout, cptp=cptp)
-            ms = peng.timer_end() / 5
+            ms = timed(lambda: peng.lifp_dev(pc, pout, cptp=cptp), 5, peng)
             others["configs[2] lifp" + (" + CPTP projection" if cptp else "")] = {
                 "batch": pb, "ms_per_launch": round(ms, 4), "value": round(pb / ms * 1e3, 1), "unit": "Choi reconstructions/s"}
         del pc, pout
-        # configs[4]: 5-qubit MLE, tensor-product Pauli POVM, 1e6 shots per setting (per-GPU figure)
+        # host-pointer API (NumPy in, NumPy out): H2D of the counts + kernel + D2H of rho + synchronise, MEASURED
+        reps = 50
+        eng.mle(counts)
+        th = time.perf_counter()
+        for _ in range(reps):
+            eng.mle(counts)
+        hp = (time.perf_counter() - th) / reps
+        others["configs[1] through host pointers (PCIe-inclusive, never `value`)"] = {
+            "batch": B, "ms_per_call": round(hp * 1e3, 4), "value": round(B / hp, 1), "unit": "reconstructions/s",
+            "includes": "H2D 1.7 KB/trial, kernel, D2H 1 KB/trial + nit/nfev/fun/status, stream synchronise, ctypes marshalling"}
+        # assembly kernels (a1, a2): HBM write rate of the 5-qubit POVM tensor and Pauli basis
+        e5 = qp.get_engine(5)
+        t5 = torch.empty((243, 32, 1024), dtype=torch.float64, device="cuda")
+        tab = torch.from_numpy(np.ascontiguousarray(qp.measurements._ONE_QUBIT["proj-set"]())).cuda()
+        ms = timed(lambda: e5.povm_kron_dev(tab, t5), 10, e5)
+        others["a2 qt_povm_kron n=5 (243 x 32 x 1024 f64)"] = {"ms": round(ms, 4), "GBps": round(t5.numel() * 8 / ms / 1e6, 1),
+                                                               "frac_hbm": round(t5.numel() * 8 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        del t5
+
+    # ---- configs[4]: 5-qubit MLE, tensor-product Pauli POVM, 1e6 shots per setting; 256 trials PER RANK (weak) ----
+    c4 = None
+    if not args.no_other_configs:
         n5 = 5
         rho5 = ginibre(np.random.default_rng(1234), 2**n5)
         povm5 = qp.generate_measurement_matrix("proj-set", n5)
         shots5 = np.ones(povm5.shape[0]) * 10**6
-        np.random.seed(7)
+        np.random.seed(7 + rank)
         few = np.stack([simulate_counts(povm5, qp.Qobj(rho5).bloch, shots5) for _ in range(8)])
         b5 = 256
-        e5 = qp.get_engine(n5, device=dev_index)
+        e5 = qp.get_engine(n5)
         e5.set_povm(povm5, shots5)
         c5 = torch.from_numpy(np.ascontiguousarray(np.concatenate([few] * (b5 // 8)))).cuda()
         r5 = torch.empty((b5, 32, 32), dtype=torch.complex128, device="cuda")
         st5 = torch.zeros(b5, dtype=torch.int32, device="cuda")
-        for name, fn in (("lin", lambda: e5.lin_dev(c5, r5)), ("mle", lambda: e5.mle_dev(c5, r5, status=st5))):
+        ni5 = torch.zeros(b5, dtype=torch.int32, device="cuda")
+        c4 = {"batch_per_gpu": b5, "scaling": "weak", "n_gpus": world}
+        for name, fn in (("lin", lambda: e5.lin_dev(c5, r5)), ("mle", lambda: e5.mle_dev(c5, r5, status=st5, nit=ni5))):
             fn()
             e5.sync()
-            e5.timer_begin()
+            torch.cuda.synchronize()
+            barrier()
+            tw = time.perf_counter()
             for _ in range(5):
                 fn()
-            ms = e5.timer_end() / 5
-            others[f"configs[4] 5-qubit {name}"] = {"batch": b5, "ms_per_launch": round(ms, 4),
-                                                   "value": round(b5 / ms * 1e3, 1), "unit": "reconstructions/s"}
+            e5.sync()
+            torch.cuda.synchronize()
+            barrier()
+            dt = max_over_ranks(time.perf_counter() - tw) / 5
+            c4[name] = {"ms_per_launch": round(dt * 1e3, 4), "value": round(world * b5 / dt, 1), "unit": "reconstructions/s"}
+        bytes5 = 8 * 7776 + 16 * 1024
+        c4["mle"]["hbm_GBps_per_gpu"] = round(bytes5 * b5 / (c4["mle"]["ms_per_launch"] * 1e-3) / 1e9, 2)
+        c4["mle"]["mean_nit"] = float(ni5.float().mean().item())
         assert int(st5.sum().item()) == 0
         del c5, r5
 
-    # ---- bootstrap CI (configs[3]): strong scaling over ranks, one all-gather -------------------
-    boot = None
+    # ---- bootstrap CIs: strong scaling over ranks, one all-gather each ---------------------------
+    def bootstrap_leg(engine, resamples, centre_matrix, dd, tile=1):
+        """Time reconstruct (this rank's shard) + distances + ONE all-gather + sort + quantiles.  `resamples` is
+        the full (n, S, K) host array (identical on every rank); `tile` repeats this rank's shard on the device."""
+        n_tot = len(resamples) * tile
+        lo, hi = qd.shard_bounds(n_tot)
+        idx = np.arange(lo, hi) % len(resamples)
+        shard = torch.from_numpy(np.ascontiguousarray(resamples[idx])).cuda()
+        rho_b = torch.empty((hi - lo, dd, dd), dtype=torch.complex128, device="cuda")
+        dist_b = torch.empty(hi - lo, dtype=torch.float64, device="cuda")
+        centre_d = torch.from_numpy(np.ascontiguousarray(centre_matrix)).cuda()
+        levels = [0.5, 0.9, 0.95]
+
+        def run():
+            engine.mle_dev(shard, rho_b)
+            engine.hs_dist_dev(rho_b, centre_d, dist_b)
+            full = qd.allgather_device(dist_b, n_tot)
+            if full.data_ptr() == dist_b.data_ptr():
+                full = full.clone()
+            return engine.sort_quantiles(full, levels)  # synchronises
+
+        run()  # warm-up (allocations, RCCL channel set-up)
+        torch.cuda.synchronize()
+        barrier()
+        tb = time.perf_counter()
+        q = run()
+        torch.cuda.synchronize()
+        barrier()
+        ms = max_over_ranks((time.perf_counter() - tb) * 1e3)
+        return {"n_points": n_tot, "wall_ms": round(ms, 3), "scaling": "strong", "n_gpus": world,
+                "quantiles_hs": [round(float(x), 8) for x in q], "conf_levels": levels,
+                "timed": "reconstruct + distances + all-gather + device sort + quantiles "
+                         "(resampling on the host RNG is input generation)"}
+
+    boot = boot5 = boot_large = None
     if args.bootstrap_points > 0:
         tmg = qp.StateTomograph(state)
         tmg.povm_matrix = povm
         tmg.results = all_counts[0]
         centre = tmg.point_estimate("mle")
         np.random.seed(4242)
-        # draw the resamples first (host RNG, untimed input generation), then time reconstruction
-        # + distances + gather + quantiles  (what BootstrapStateInterval.setup does, split for timing)
-        res = [simulate_counts(povm, centre.bloch, tmg.n_measurements) for _ in range(args.bootstrap_points)]
-        res = np.stack(res)
-        from quantpy_amd import distributed as qd
-
-        lo, hi = qd.shard_bounds(len(res))
-        shard_d = torch.from_numpy(np.ascontiguousarray(res[lo:hi])).cuda()
-        rho_b = torch.empty((hi - lo, d, d), dtype=torch.complex128, device="cuda")
-        dist_b = torch.empty(hi - lo, dtype=torch.float64, device="cuda")
-        centre_d = torch.from_numpy(np.ascontiguousarray(centre.matrix)).cuda()
-        torch.cuda.synchronize()
-        barrier()
-        tb = time.perf_counter()
-        eng.mle_dev(shard_d, rho_b)
-        eng.hs_dist_dev(rho_b, centre_d, dist_b)
-        eng.sync()
-        full = qd.allgather_concat(dist_b.cpu().numpy(), len(res))
-        q = np.interp([0.5, 0.9, 0.95], np.linspace(0, 1, len(full)), np.sort(full))
-        torch.cuda.synchronize()
-        barrier()
-        boot_ms = (time.perf_counter() - tb) * 1e3
-        if use_dist:
-            t = torch.tensor([boot_ms], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            boot_ms = float(t.item())
-        boot = {"n_points": args.bootstrap_points, "wall_ms": round(boot_ms, 3), "scaling": "strong",
-                "quantiles_hs": [round(float(x), 8) for x in q], "conf_levels": [0.5, 0.9, 0.95],
-                "timed": "reconstruct + distances + all-gather + quantiles (resampling on the host RNG is input generation)"}
+        res = np.stack([simulate_counts(povm, centre.bloch, tmg.n_measurements) for _ in range(args.bootstrap_points)])
+        boot = bootstrap_leg(eng, res, centre.matrix, d)
+        if args.bootstrap_large > 0:
+            distinct = min(args.bootstrap_large, 32768)
+            pool = vector_resamples(povm, centre.bloch, tmg.n_measurements, distinct, 99)
+            tile = max(1, args.bootstrap_large // distinct)
+            boot_large = bootstrap_leg(eng, pool, centre.matrix, d, tile=tile)
+            boot_large["input"] = f"{distinct} distinct resamples (vectorised Generator draws) tiled x{tile} on the device"
+        if not args.no_other_configs:
+            t5 = qp.StateTomograph(qp.Qobj(rho5))
+            t5.povm_matrix = povm5
+            t5.results = few[0]
+            centre5 = t5.point_estimate("mle")
+            pool5 = vector_resamples(povm5, centre5.bloch, t5.n_measurements, args.bootstrap_points, 98)
+            boot5 = bootstrap_leg(e5, pool5, centre5.matrix, 32)
+            boot5["input"] = "resamples drawn setting by setting in vectorised Generator calls"
 
     # ---- CPU baseline: the oracle on a bounded sample, one host core (rank 0, N = 1 only) -------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import quantpy_oracle as qo
-
+        qo = _oracle()
         try:
             from threadpoolctl import threadpool_limits
 
@@ -366,15 +544,16 @@ def main():
         except Exception:
             limiter = None
         ns = args.cpu_sample
+        povm_np = np.asarray(povm)
         tc = time.perf_counter()
         worst = 0.0
         for i in range(ns):
-            ref = qo.mle_estimate(counts[i % B], povm)
+            ref = qo.mle_estimate(counts[i % B], povm_np)
             if i < 64:
                 worst = max(worst, abs(qo.infidelity(ref, rho_h[i])))
         cpu_s = time.perf_counter() - tc
-        if limiter is not None:
-            limiter.unregister() if hasattr(limiter, "unregister") else None
+        if limiter is not None and hasattr(limiter, "restore_original_limits"):
+            limiter.restore_original_limits()
         cpu = {"value": round(ns / cpu_s, 3), "unit": "reconstructions/s", "cores": 1, "kind": "port",
                "sample": f"{ns} reconstructions cycling over the {B} trials of this workload, oracle/quantpy_oracle.mle_estimate "
                          f"(scipy BFGS + forward differences = the reference's algorithm), {cpu_s:.1f} s",
@@ -392,14 +571,19 @@ def main():
                                    "1e5 shots/setting, point_estimate('mle'), 1k-trial batch per GPU",
                        "n_qubits": n, "batch_per_gpu": B, "shots_per_setting": args.shots, "povm": "proj-set",
                        "parallelism": f"trials sharded over {world} GPU(s), no data-path collective"},
+            "rccl_ranks": rccl_ranks, "backend": (args.backend if use_dist else None),
             "bfgs": {"mean_nit": float(nit.mean()), "mean_nfev": float(nfev.mean()),
                      "reference_equivalent_nfev": float(nfev.mean()) * (D + 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "saturated_batch": sat,
+            "iterating": iterating,
             "two_stream_pipeline": piped,
             "other_configs": others,
+            "configs4_weak": c4,
             "bootstrap_ci": boot,
+            "bootstrap_ci_n5": boot5,
+            "bootstrap_ci_large": boot_large,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

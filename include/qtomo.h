@@ -60,7 +60,16 @@ int qt_device_count(void);
 qt_handle_t* qt_create(int device, int n_qubits);
 void qt_destroy(qt_handle_t* h);
 int qt_sync(qt_handle_t* h);
-/* run the handle's work on an existing hipStream_t (e.g. torch's current stream); NULL = own */
+/* Run the handle's work on an existing hipStream_t (e.g. torch's current stream); NULL = a private
+ * non-blocking stream (the default after qt_create); QT_STREAM_LEGACY = the legacy default ("null")
+ * stream, which is what a framework means by stream 0.
+ * ORDERING CONTRACT of device-pointer calls (flags & QT_DEVICE_PTR): they are enqueued on the handle's
+ * stream and return at once.  Inputs must have been produced on that stream, or by work the caller has
+ * already ordered before it (event / synchronize); outputs may be consumed on that stream, after
+ * qt_sync, or after the caller's own event on it.  A caller whose producers run on another stream
+ * (torch's current stream, say) either binds the handle to that stream with qt_set_stream or orders
+ * the two streams itself.  Every call leaves the calling thread's current HIP device unchanged. */
+#define QT_STREAM_LEGACY ((void*)1)
 int qt_set_stream(qt_handle_t* h, void* hip_stream);
 /* hipEvent timers on the handle's stream: begin, ..., end -> elapsed milliseconds */
 int qt_timer_begin(qt_handle_t* h);
@@ -129,6 +138,14 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
 /* ---- a16: quantpy/geometry.py:5-20 hs_dst --------------------------------------------------- */
 /* dist[b] = sqrt(|Tr((rho_b - centre)^2)|) / sqrt(2), set to 0 below 1e-15 */
 int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, int B, double* dist, int flags);
+
+/* ---- a16: quantpy/tomography/interval.py:610-612 (and :683-685) -------------------------------- */
+/* `dist.sort()`: ascending in-place sort of n float64 values (radix sort on the device; NaN last). */
+int qt_sort_f64(qt_handle_t* h, double* x, long long n, int flags);
+/* `interp1d(np.linspace(0, 1, n), sorted)(conf_levels)`: scipy's linear interpolation on the grid
+ * x_i = i / (n - 1); out[n_levels].  A level outside [0, 1] gives NaN (interp1d raises there). */
+int qt_sorted_quantiles(qt_handle_t* h, const double* sorted, long long n, const double* conf_levels, int n_levels,
+                        double* out, int flags);
 
 /* Metropolis-Hastings chains on the Cholesky parameters (mhmc.py:80-119 with `normalized_update`, used by
  * MHMCStateInterval, interval.py:735-750): C independent chains (the reference runs one), each on its

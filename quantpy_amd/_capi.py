@@ -11,6 +11,7 @@ QT_HOST_PTR = 0
 QT_DEVICE_PTR = 1
 QT_INIT_LIN = 0
 QT_INIT_MIXED = 1
+QT_STREAM_LEGACY = 1  # qt_set_stream: the legacy default ("null") stream
 
 # status codes (include/qtomo.h)
 QT_ERR_ARG, QT_ERR_STATE, QT_ERR_HIP, QT_ERR_SINGULAR, QT_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
@@ -47,6 +48,8 @@ SIGNATURES = {
     "qt_mle_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, _vp, _vp, _vp, _vp, _c_int]),
     "qt_mhmc_state": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _c_int]),
     "qt_hs_dist_batch": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int]),
+    "qt_sort_f64": (_c_int, [_vp, _vp, ctypes.c_longlong, _c_int]),
+    "qt_sorted_quantiles": (_c_int, [_vp, _vp, ctypes.c_longlong, _vp, _c_int, _vp, _c_int]),
     "qt_process_setup": (_c_int, [_vp, _vp, _c_int]),
     "qt_process_get_operators": (_c_int, [_vp, _vp, _vp, _c_int]),
     "qt_lifp_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _c_int]),

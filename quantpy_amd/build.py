@@ -22,12 +22,26 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _source_hash():
+    """SHA-256 over the HIP sources, the public header and the compiler flags."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(SCHED_FLAGS).encode())
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(os.path.dirname(_HERE), "include", "qtomo.h")]
+    for path in srcs:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    """True unless lib/libqtomo.so was built from exactly the sources in the tree (hash, not mtime: a shipped
+    library newer than edited-and-reverted or freshly checked-out sources must not be trusted on its date)."""
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".srchash"):
         return True
-    t = os.path.getmtime(LIB)
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(_HERE), "include", "qtomo.h")]
-    return any(os.path.getmtime(s) > t for s in srcs)
+    with open(LIB + ".srchash") as fh:
+        return fh.read().strip() != _source_hash()
 
 
 def build_profile_library(verbose=False):
@@ -54,4 +68,6 @@ def build_library(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    with open(LIB + ".srchash", "w") as fh:
+        fh.write(_source_hash() + "\n")
     return LIB

@@ -534,4 +534,33 @@ __global__ void __launch_bounds__(64) k_hs_dist(int d, const double* __restrict_
   }
 }
 
+// ---- a16: interval.py:610-612  interp1d(linspace(0, 1, n), sorted_dist)(conf_levels) -------------
+// scipy's linear interp1d: hi = searchsorted(x, q) clipped to [1, n-1], lo = hi - 1,
+// y = (y_hi - y_lo) / (x_hi - x_lo) * (q - x_lo) + y_lo, with x_i = i * (1 / (n - 1)) and x_(n-1) = 1 exactly
+// (np.linspace).  q outside [0, 1] gives NaN (interp1d raises; the Python layer checks first).
+__global__ void k_interp_sorted(const double* __restrict__ y, long long n, const double* __restrict__ q, int nq,
+                                double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nq) return;
+  const double x = q[t];
+  if (!(x >= 0.0 && x <= 1.0) || n < 1) {
+    out[t] = __builtin_nan("");
+    return;
+  }
+  if (n == 1) {
+    out[t] = y[0];
+    return;
+  }
+  const double step = 1.0 / (double)(n - 1);
+  auto grid = [&](long long i) { return i == n - 1 ? 1.0 : (double)i * step; };
+  long long hi = (long long)(x * (double)(n - 1));  // close to the answer; fix up against the actual grid values
+  if (hi > n - 1) hi = n - 1;
+  while (hi > 0 && grid(hi - 1) >= x) --hi;  // smallest i with grid(i) >= x  (searchsorted side='left')
+  while (hi < n - 1 && grid(hi) < x) ++hi;
+  if (hi < 1) hi = 1;
+  const long long lo = hi - 1;
+  const double xl = grid(lo), xh = grid(hi), yl = y[lo], yh = y[hi];
+  out[t] = (yh - yl) / (xh - xl) * (x - xl) + yl;
+}
+
 }  // namespace qt

@@ -1,6 +1,7 @@
 // libqtomo.so -- C ABI (include/qtomo.h) over the HIP kernels in qt_small.h / qt_ops.h /
 // qt_process.h.  gfx950 only.  There is no CPU implementation behind these entry points.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -79,6 +80,8 @@ struct qt_handle {
   DevBuf ws_x, ws_g, ws_f, ws_act;
   // BFGS (s, y) history of the n >= 4 kernels (max_iter x 2 D doubles per trial of a chunk)
   DevBuf hess;
+  // radix-sort double buffer + temporary storage (qt_sort_f64)
+  DevBuf sort_alt, sort_tmp;
   // process tomography
   qt::ProcessState proc;
   bool proc_set = false;
@@ -91,12 +94,27 @@ struct qt_handle {
 
 namespace {
 
-int check_handle(qt_handle_t* h) {
-  if (!h) return fail(QT_ERR_ARG, "null handle");
-  hipError_t e = hipSetDevice(h->device);
-  if (e != hipSuccess) return fail(QT_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
-  return 0;
-}
+// Every entry point runs on the handle's device and leaves the calling thread's current device as it found
+// it: a caller that shares the process with PyTorch (one rank per GPU) must not see torch's current device
+// move because an engine call happened to target another card.
+struct DeviceScope {
+  int prev = -1, want = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int device) : want(device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != want) err = hipSetDevice(want);
+  }
+  ~DeviceScope() {
+    if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+#define QT_ENTER(h)                                                                                          \
+  if (!(h)) return fail(QT_ERR_ARG, "null handle");                                                          \
+  DeviceScope qt_scope_((h)->device);                                                                        \
+  if (qt_scope_.err != hipSuccess) return fail(QT_ERR_HIP, "hipSetDevice(%d): %s", (h)->device, hipGetErrorString(qt_scope_.err))
 
 inline int grid_for(size_t total, int block = 256, int cap = 8192) {
   size_t g = (total + block - 1) / block;
@@ -274,8 +292,9 @@ qt_handle_t* qt_create(int device, int n_qubits) {
     fail(QT_ERR_ARG, "device %d out of range (have %d)", device, n);
     return nullptr;
   }
-  if ((e = hipSetDevice(device)) != hipSuccess) {
-    fail(QT_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  DeviceScope scope(device);
+  if (scope.err != hipSuccess) {
+    fail(QT_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(scope.err));
     return nullptr;
   }
   qt_handle_t* h = new qt_handle();
@@ -295,12 +314,12 @@ qt_handle_t* qt_create(int device, int n_qubits) {
 
 void qt_destroy(qt_handle_t* h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DeviceScope scope(h->device);
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->pr_T, &h->pr_P1, &h->pr_P1T, &h->pr_wrow, &h->pr_rmap, &h->pr_fwd, &h->pr_bwd, &h->pr_aug}) b->release();
   for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->in0, &h->in1,
                     &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug, &h->ws_x, &h->ws_g, &h->ws_f,
-                    &h->ws_act, &h->hess})
+                    &h->ws_act, &h->hess, &h->sort_alt, &h->sort_tmp})
     b->release();
   h->proc.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -310,17 +329,17 @@ void qt_destroy(qt_handle_t* h) {
 }
 
 int qt_sync(qt_handle_t* h) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
 int qt_set_stream(qt_handle_t* h, void* hip_stream) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->own_stream && h->stream) HIPCHK(hipStreamDestroy(h->stream));
   if (hip_stream) {
-    h->stream = static_cast<hipStream_t>(hip_stream);
+    h->stream = hip_stream == QT_STREAM_LEGACY ? hipStreamLegacy : static_cast<hipStream_t>(hip_stream);
     h->own_stream = false;
   } else {
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -330,13 +349,13 @@ int qt_set_stream(qt_handle_t* h, void* hip_stream) {
 }
 
 int qt_timer_begin(qt_handle_t* h) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   return 0;
 }
 
 int qt_timer_end(qt_handle_t* h, double* elapsed_ms) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!elapsed_ms) return fail(QT_ERR_ARG, "null elapsed_ms");
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventSynchronize(h->ev1));
@@ -347,7 +366,7 @@ int qt_timer_end(qt_handle_t* h, double* elapsed_ms) {
 }
 
 int qt_pauli_basis(qt_handle_t* h, double* out, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!out) return fail(QT_ERR_ARG, "null out");
   const size_t n = (size_t)h->D * h->D * 2;
   double* dout;
@@ -358,7 +377,7 @@ int qt_pauli_basis(qt_handle_t* h, double* out, int flags) {
 }
 
 int qt_povm_kron(qt_handle_t* h, const double* povm1, int S1, int K1, double* out, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!povm1 || !out || S1 < 1 || K1 < 1) return fail(QT_ERR_ARG, "bad povm_kron arguments");
   size_t S = 1, K = 1;
   for (int q = 0; q < h->nq; ++q) {
@@ -439,7 +458,7 @@ static int alloc_povm(qt_handle_t* h, int S, int K) {
 }
 
 int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!A || !Ns || S < 1 || K < 1) return fail(QT_ERR_ARG, "bad set_povm arguments");
   if (int r = alloc_povm(h, S, K)) return r;
   const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -449,7 +468,7 @@ int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns,
 }
 
 int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, const double* Ns, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!povm1 || !Ns || S1 < 1 || K1 < 1) return fail(QT_ERR_ARG, "bad set_povm_product arguments");
   const int n = h->nq, D = h->D, R1 = S1 * K1;
   long long S = 1, K = 1, M = 1;
@@ -559,7 +578,7 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
 }
 
 int qt_get_left_inverse(qt_handle_t* h, double* out, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (int r = need_povm(h)) return r;
   if (!out) return fail(QT_ERR_ARG, "null out");
   if (!h->pinv_ready)
@@ -571,7 +590,7 @@ int qt_get_left_inverse(qt_handle_t* h, double* out, int flags) {
 }
 
 int qt_born_probs(qt_handle_t* h, const double* bloch, int B, double* p, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (int r = need_povm(h)) return r;
   if (B < 0 || (B > 0 && (!bloch || !p))) return fail(QT_ERR_ARG, "bad born_probs arguments");
   if (B == 0) return 0;
@@ -627,7 +646,7 @@ int qt_born_probs(qt_handle_t* h, const double* bloch, int B, double* p, int fla
 }
 
 int qt_bloch_from_mat(qt_handle_t* h, const double* mat, int B, double* bloch, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (B < 0 || (B > 0 && (!mat || !bloch))) return fail(QT_ERR_ARG, "bad bloch_from_mat arguments");
   if (B == 0) return 0;
   const double* din;
@@ -641,7 +660,7 @@ int qt_bloch_from_mat(qt_handle_t* h, const double* mat, int B, double* bloch, i
 }
 
 int qt_mat_from_bloch(qt_handle_t* h, const double* bloch, int B, double* mat, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (B < 0 || (B > 0 && (!mat || !bloch))) return fail(QT_ERR_ARG, "bad mat_from_bloch arguments");
   if (B == 0) return 0;
   const double* din;
@@ -656,7 +675,7 @@ int qt_mat_from_bloch(qt_handle_t* h, const double* bloch, int B, double* mat, i
 
 int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, double* rho, double* bloch_out,
                  int32_t* status, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (int r = need_povm(h)) return r;
   if (B < 0 || (B > 0 && (!counts || !rho))) return fail(QT_ERR_ARG, "bad lin_batch arguments");
   if (B == 0) return 0;
@@ -682,7 +701,7 @@ int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, dou
 }
 
 int qt_chol_param(qt_handle_t* h, const double* rho, int B, double* x, int32_t* status, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (B < 0 || (B > 0 && (!rho || !x))) return fail(QT_ERR_ARG, "bad chol_param arguments");
   if (B == 0) return 0;
   const double* din;
@@ -705,7 +724,7 @@ int qt_chol_param(qt_handle_t* h, const double* rho, int B, double* x, int32_t* 
 }
 
 int qt_chol_unparam(qt_handle_t* h, const double* x, int B, double* LLh, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (B < 0 || (B > 0 && (!x || !LLh))) return fail(QT_ERR_ARG, "bad chol_unparam arguments");
   if (B == 0) return 0;
   const double* din;
@@ -724,7 +743,7 @@ int qt_chol_unparam(qt_handle_t* h, const double* x, int B, double* LLh, int fla
 }
 
 int qt_nll_batch(qt_handle_t* h, const double* x, const int64_t* counts, int B, double* f, double* grad, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (int r = need_povm(h)) return r;
   if (B < 0 || (B > 0 && (!x || !counts || !f))) return fail(QT_ERR_ARG, "bad nll_batch arguments");
   if (B == 0) return 0;
@@ -749,7 +768,7 @@ int qt_nll_batch(qt_handle_t* h, const double* x, const int64_t* counts, int B, 
 
 int qt_mhmc_state(qt_handle_t* h, const int64_t* counts, int C, const double* x_init, const double* deltas,
                   const double* uniforms, int T, double step, double* chain, int32_t* accepted, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (int r = need_povm(h)) return r;
   if (C < 0 || T < 0 || (C > 0 && T > 0 && (!counts || !x_init || !deltas || !uniforms || !chain || !accepted)))
     return fail(QT_ERR_ARG, "bad mhmc_state arguments");
@@ -774,7 +793,7 @@ int qt_mhmc_state(qt_handle_t* h, const int64_t* counts, int C, const double* x_
 
 int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol, double* rho,
                  int32_t* nit, int32_t* nfev, double* fun, int32_t* status, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (int r = need_povm(h)) return r;
   if (B < 0 || (B > 0 && (!counts || !rho))) return fail(QT_ERR_ARG, "bad mle_batch arguments");
   if (init != QT_INIT_LIN && init != QT_INIT_MIXED) return fail(QT_ERR_ARG, "init must be QT_INIT_LIN or QT_INIT_MIXED");
@@ -835,7 +854,7 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
 }
 
 int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, int B, double* dist, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (B < 0 || (B > 0 && (!rho || !centre || !dist))) return fail(QT_ERR_ARG, "bad hs_dist arguments");
   if (B == 0) return 0;
   const double *dr, *dcn;
@@ -848,9 +867,46 @@ int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, in
   return finish(h, flags);
 }
 
+// ---- a16: interval.py:610-612 ------------------------------------------------------------------------
+int qt_sort_f64(qt_handle_t* h, double* x, long long n, int flags) {
+  QT_ENTER(h);
+  if (n < 0 || (n > 0 && !x)) return fail(QT_ERR_ARG, "bad sort arguments");
+  if (n > 0x7fffffffLL) return fail(QT_ERR_UNSUPPORTED, "qt_sort_f64 sorts at most 2^31 - 1 values");
+  if (n == 0) return 0;
+  const double* din;
+  if (int r = stage_in(h, h->in0, (const double*)x, (size_t)n, flags, &din)) return r;
+  double* dx = const_cast<double*>(din);
+  HIPCHK(h->sort_alt.ensure((size_t)n * sizeof(double)));
+  hipcub::DoubleBuffer<double> keys(dx, h->sort_alt.as<double>());
+  size_t tmp_bytes = 0;
+  HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys, (int)n, 0, 64, h->stream));
+  HIPCHK(h->sort_tmp.ensure(tmp_bytes));
+  HIPCHK(hipcub::DeviceRadixSort::SortKeys(h->sort_tmp.p, tmp_bytes, keys, (int)n, 0, 64, h->stream));
+  if (keys.Current() != dx)
+    HIPCHK(hipMemcpyAsync(dx, keys.Current(), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (int r = fetch_out(h, (const double*)dx, x, (size_t)n, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_sorted_quantiles(qt_handle_t* h, const double* sorted, long long n, const double* conf_levels, int n_levels,
+                        double* out, int flags) {
+  QT_ENTER(h);
+  if (n < 1 || n_levels < 0 || !sorted || (n_levels > 0 && (!conf_levels || !out)))
+    return fail(QT_ERR_ARG, "bad sorted_quantiles arguments");
+  if (n_levels == 0) return 0;
+  const double *ds, *dq;
+  double* dout;
+  if (int r = stage_in(h, h->in0, sorted, (size_t)n, flags, &ds)) return r;
+  if (int r = stage_in(h, h->in1, conf_levels, (size_t)n_levels, flags, &dq)) return r;
+  if (int r = stage_out(h, h->out0, out, (size_t)n_levels, flags, &dout)) return r;
+  hipLaunchKernelGGL(qt::k_interp_sorted, dim3((n_levels + 255) / 256), dim3(256), 0, h->stream, ds, n, dq, n_levels, dout);
+  if (int r = fetch_out(h, dout, out, (size_t)n_levels, flags)) return r;
+  return finish(h, flags);
+}
+
 // ---- a5 for arbitrary matrices: routines.py:69-71 -------------------------------------------------
 int qt_left_inverse(qt_handle_t* h, const double* A, int rows, int cols, int is_complex, double* out, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!A || !out || rows < 1 || cols < 1) return fail(QT_ERR_ARG, "bad left_inverse arguments");
   if (rows < cols) return fail(QT_ERR_SINGULAR, "matrix has fewer rows (%d) than columns (%d)", rows, cols);
   const int W = is_complex ? 2 : 1;
@@ -886,7 +942,7 @@ int qt_left_inverse(qt_handle_t* h, const double* A, int rows, int cols, int is_
 
 // ---- process tomography: qt_process.h -------------------------------------------------------------
 int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (int r = need_povm(h)) return r;
   if (!in_states) return fail(QT_ERR_ARG, "null in_states");
   if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "process tomography supports n_qubits 1..2 in this release");
@@ -927,7 +983,7 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
 }
 
 int qt_process_get_operators(qt_handle_t* h, double* lifp_oper, double* lifp_oper_inv, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
   const size_t bytes = (size_t)h->D * h->M * h->D * h->D * 2 * sizeof(double);
   const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -938,7 +994,7 @@ int qt_process_get_operators(qt_handle_t* h, double* lifp_oper, double* lifp_ope
 
 int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double* choi, int32_t* iters, int32_t* status,
                   int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
   if (B < 0 || (B > 0 && (!counts || !choi))) return fail(QT_ERR_ARG, "bad lifp_batch arguments");
   if (B == 0) return 0;
@@ -993,7 +1049,7 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
 
 int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, double tol, int stop_rule, double* choi,
                   int32_t* iters, int32_t* status, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
   if (B < 0 || (B > 0 && (!counts || !choi))) return fail(QT_ERR_ARG, "bad pgdb_batch arguments");
   if (stop_rule != 0 && stop_rule != 1) return fail(QT_ERR_ARG, "stop_rule must be 0 (reference) or 1 (converged)");
@@ -1024,7 +1080,7 @@ int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, doub
 
 int qt_mhmc_process(qt_handle_t* h, const int64_t* counts, int C, const double* choi_init, const double* deltas,
                     const double* uniforms, int T, double step, double* chain, int32_t* accepted, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
   if (C < 0 || T < 0 || (C > 0 && T > 0 && (!counts || !choi_init || !deltas || !uniforms || !chain || !accepted)))
     return fail(QT_ERR_ARG, "bad mhmc_process arguments");
@@ -1056,7 +1112,7 @@ int qt_mhmc_process(qt_handle_t* h, const int64_t* counts, int C, const double* 
 
 int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode, int n_iter, double tol, double* choi_out,
                           int32_t* iters, int flags) {
-  if (int r = check_handle(h)) return r;
+  QT_ENTER(h);
   if (B < 0 || (B > 0 && (!choi_in || !choi_out))) return fail(QT_ERR_ARG, "bad cptp_project arguments");
   if (mode < 0 || mode > 2) return fail(QT_ERR_ARG, "mode must be 0 (CPTP), 1 (TP) or 2 (CP)");
   if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "process tomography supports n_qubits 1..2 in this release");

@@ -76,6 +76,35 @@ def allgather_concat(local, n_total):
     return np.concatenate(parts)
 
 
+def allgather_device(local, n_total):
+    """Device-tensor form of `allgather_concat`: `local` is this rank's 1-D float64 torch tensor (its
+    `shard_bounds(n_total)` slice); returns the full length-`n_total` tensor on the same device on every rank.
+    With the `nccl` group this is ONE RCCL all-gather over xGMI, enqueued behind the producer of `local` on
+    torch's current stream (the engine's device-pointer calls run there), and nothing goes through the host;
+    with `gloo` the shard takes the host path."""
+    import torch
+
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return local
+    ws = dist.get_world_size()
+    sizes = [shard_bounds(n_total, r, ws) for r in range(ws)]
+    width = max(hi - lo for lo, hi in sizes)
+    if dist.get_backend() != "nccl":
+        full = allgather_concat(local.detach().cpu().numpy(), n_total)
+        return torch.from_numpy(full).to(local.device)
+    if local.shape[0] == width:
+        buf = local.contiguous()
+    else:
+        buf = torch.zeros(width, dtype=torch.float64, device=local.device)
+        buf[: local.shape[0]] = local
+    out = torch.empty(ws * width, dtype=torch.float64, device=local.device)
+    dist.all_gather_into_tensor(out, buf)
+    if all(hi - lo == width for lo, hi in sizes):
+        return out
+    return torch.cat([out[r * width: r * width + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
+
+
 def sharded_map(items, fn):
     """Apply `fn(items[lo:hi]) -> 1-D float64 array` to this rank's slice and all-gather."""
     n = len(items)

@@ -5,6 +5,8 @@ HIP kernels.  Inputs are NumPy arrays (host-pointer calls, synchronous) or torch
 (device-pointer calls, asynchronous on the engine's stream; outputs must then be passed in).
 """
 import ctypes
+import os
+import sys
 
 import numpy as np
 
@@ -55,19 +57,45 @@ def _i64(a):
     return np.ascontiguousarray(a)
 
 
-class Engine:
-    """Owns a qt_handle (device buffers, stream, cached POVM operators) for `n_qubits`."""
+def default_device():
+    """The device index an engine is created on when the caller names none: the process's own GPU.
+    `QTOMO_DEVICE` if set; else torch's current device once torch has initialised the GPU (one rank
+    per GPU: torch.cuda.set_device(local_rank) happened first); else `LOCAL_RANK` (torchrun) clamped
+    to the visible devices; else 0."""
+    env = os.environ.get("QTOMO_DEVICE")
+    if env is not None:
+        return int(env)
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        return int(torch.cuda.current_device())
+    lr = os.environ.get("LOCAL_RANK")
+    if lr is not None:
+        return int(lr)
+    return 0
 
-    def __init__(self, n_qubits, device=0):
+
+class Engine:
+    """Owns a qt_handle (device buffers, stream, cached POVM operators) for `n_qubits`.
+
+    Host-pointer (NumPy) calls are synchronous.  Device-pointer (`*_dev`, torch tensors) calls are
+    asynchronous on the handle's stream; the first of them binds the handle to torch's current
+    stream (`bind_torch_stream`), so that they are ordered with the torch work that produced their
+    inputs and consumes their outputs.  `stream="own"` keeps a private non-blocking stream instead
+    (the caller then orders producers / consumers itself: `sync()`)."""
+
+    def __init__(self, n_qubits, device=None, stream="torch"):
         self.lib = _capi.load()
         self.n = int(n_qubits)
         self.d = 2**self.n
         self.D = 4**self.n
-        self.device = device
-        self._h = self.lib.qt_create(device, self.n)
+        self.device = default_device() if device is None else int(device)
+        self._h = self.lib.qt_create(self.device, self.n)
         if not self._h:
             raise _capi.EngineUnavailable(_capi.last_error())
         self._povm_key = None
+        self._proc_key = None
+        self._stream_policy = stream
+        self._stream_bound = stream == "own"
         self.S = self.K = self.M = 0
 
     def close(self):
@@ -91,7 +119,21 @@ class Engine:
         self._chk(self.lib.qt_sync(self._h))
 
     def set_stream(self, stream_ptr):
-        self._chk(self.lib.qt_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+        """Bind to a hipStream_t given as an integer; 0 / None = a private stream, 1 = the legacy default stream."""
+        self._chk(self.lib.qt_set_stream(self._h, ctypes.c_void_p(stream_ptr or None)))
+        self._stream_bound = True
+
+    def bind_torch_stream(self):
+        """Run this engine's work on torch's current stream of its device (stream 0 = the legacy default
+        stream).  Called by the first device-pointer call; call it again after switching torch streams."""
+        import torch
+
+        ptr = int(torch.cuda.current_stream(self.device).cuda_stream)
+        self.set_stream(ptr if ptr else _capi.QT_STREAM_LEGACY)
+
+    def _dev_call(self):
+        if not self._stream_bound:
+            self.bind_torch_stream()
 
     def timer_begin(self):
         self._chk(self.lib.qt_timer_begin(self._h))
@@ -118,6 +160,13 @@ class Engine:
         self._chk(self.lib.qt_povm_kron(self._h, _ptr(table), s1, k1, _ptr(out), _capi.QT_HOST_PTR))
         return out
 
+    def povm_kron_dev(self, table, out):
+        """device-pointer form: table (S1, K1, 4) float64, out (S1^n, K1^n, 4^n) float64 torch CUDA tensors"""
+        self._dev_call()
+        s1, k1 = (1, table.shape[0]) if table.dim() == 2 else table.shape[:2]
+        assert out.numel() == (s1 * k1 * 4) ** self.n
+        self._chk(self.lib.qt_povm_kron(self._h, _ptr(table), s1, k1, _ptr(out), _capi.QT_DEVICE_PTR))
+
     # ---- a5 ---------------------------------------------------------------------------------
     def set_povm(self, povm_matrix, n_meas):
         """Cache A (S, K, D), the shot weights and the left inverse.  Re-uploading the same
@@ -138,6 +187,7 @@ class Engine:
         if key == self._povm_key:
             return
         self._povm_key = None
+        self._proc_key = None  # the C side drops its process set-up with the POVM (alloc_povm: proc_set = false)
         if factor is not None and (factor.shape[0] ** self.n, factor.shape[1] ** self.n) == (s, k):
             self._chk(self.lib.qt_set_povm_product(self._h, _ptr(factor), factor.shape[0], factor.shape[1], _ptr(ns),
                                                    _capi.QT_HOST_PTR))
@@ -169,7 +219,7 @@ class Engine:
         s = _c128(in_states)
         assert s.shape == (self.D, self.d, self.d)
         key = (self._povm_key, s.tobytes())
-        if key == getattr(self, "_proc_key", None):
+        if key == self._proc_key:
             return
         self._proc_key = None
         self._chk(self.lib.qt_process_setup(self._h, _ptr(s), _capi.QT_HOST_PTR))
@@ -231,6 +281,7 @@ class Engine:
         return chain[0], acc[0]
 
     def lifp_dev(self, counts, choi, cptp=True, iters=None, status=None):
+        self._dev_call()
         self._chk(self.lib.qt_lifp_batch(self._h, _ptr(counts), counts.shape[0], int(bool(cptp)), _ptr(choi), _ptr(iters),
                                          _ptr(status), _capi.QT_DEVICE_PTR))
 
@@ -251,6 +302,7 @@ class Engine:
     # ---- a4 / a3 ----------------------------------------------------------------------------
     def born_probs(self, bloch, out=None):
         if _is_dev(bloch):
+            self._dev_call()
             b = bloch.shape[0]
             self._chk(self.lib.qt_born_probs(self._h, _ptr(bloch), b, _ptr(out), _capi.QT_DEVICE_PTR))
             return out
@@ -298,6 +350,7 @@ class Engine:
 
     def lin_dev(self, counts, rho, physical=True, bloch=None, status=None):
         """device-pointer form: counts int64 (B, S, K), rho complex128 (B, d, d) torch CUDA tensors"""
+        self._dev_call()
         self._chk(self.lib.qt_lin_batch(self._h, _ptr(counts), counts.shape[0], int(bool(physical)), _ptr(rho),
                                         _ptr(bloch), _ptr(status), _capi.QT_DEVICE_PTR))
 
@@ -368,6 +421,7 @@ class Engine:
         return (chain[0], acc[0]) if single else (chain, acc)
 
     def mle_dev(self, counts, rho, init="lin", max_iter=100, tol=1e-3, nit=None, nfev=None, fun=None, status=None):
+        self._dev_call()
         self._chk(self.lib.qt_mle_batch(self._h, _ptr(counts), counts.shape[0],
                                         _capi.QT_INIT_LIN if init == "lin" else _capi.QT_INIT_MIXED, int(max_iter),
                                         float(tol), _ptr(rho), _ptr(nit), _ptr(nfev), _ptr(fun), _ptr(status),
@@ -384,19 +438,49 @@ class Engine:
         return out[0] if single else out
 
     def hs_dist_dev(self, rho, centre, out):
+        self._dev_call()
         self._chk(self.lib.qt_hs_dist_batch(self._h, _ptr(rho), _ptr(centre), rho.shape[0], _ptr(out),
                                             _capi.QT_DEVICE_PTR))
+
+
+    def sort_quantiles(self, dist, conf_levels):
+        """interval.py:610-612 on the device: sort `dist` (NumPy array: a sorted copy is returned; torch CUDA
+        tensor: sorted in place) and evaluate interp1d(linspace(0, 1, n), dist) at `conf_levels` -> NumPy array."""
+        cl = _f64(np.atleast_1d(conf_levels))
+        if cl.size and (cl.min() < 0 or cl.max() > 1):
+            raise ValueError("A value in x_new is outside the interpolation range.")
+        if _is_dev(dist):
+            import torch
+
+            self._dev_call()
+            n = dist.numel()
+            q = torch.from_numpy(cl).to(dist.device)
+            out = torch.empty(cl.size, dtype=torch.float64, device=dist.device)
+            self._chk(self.lib.qt_sort_f64(self._h, _ptr(dist), n, _capi.QT_DEVICE_PTR))
+            self._chk(self.lib.qt_sorted_quantiles(self._h, _ptr(dist), n, _ptr(q), cl.size, _ptr(out), _capi.QT_DEVICE_PTR))
+            self.sync()
+            return out.cpu().numpy()
+        srt = _f64(dist).copy()
+        out = np.empty(cl.size)
+        self._chk(self.lib.qt_sort_f64(self._h, _ptr(srt), srt.size, _capi.QT_HOST_PTR))
+        self._chk(self.lib.qt_sorted_quantiles(self._h, _ptr(srt), srt.size, _ptr(cl), cl.size, _ptr(out), _capi.QT_HOST_PTR))
+        return srt, out
 
 
 _ENGINES = {}
 
 
-def get_engine(n_qubits, device=0):
-    """Process-wide engine cache: one handle per (n_qubits, device)."""
-    key = (int(n_qubits), int(device))
+def engine_key(n_qubits, device=None):
+    return (int(n_qubits), default_device() if device is None else int(device))
+
+
+def get_engine(n_qubits, device=None):
+    """Process-wide engine cache: one handle per (n_qubits, device); `device=None` = this process's GPU
+    (`default_device`), so that the drop-in classes of rank r run on GPU r."""
+    key = engine_key(n_qubits, device)
     eng = _ENGINES.get(key)
     if eng is None:
-        eng = _ENGINES[key] = Engine(n_qubits, device)
+        eng = _ENGINES[key] = Engine(key[0], key[1])
     return eng
 
 

@@ -20,12 +20,25 @@ _ONE_QUBIT = {
 }
 
 
+_PROBES = {}
+
+
+def _probe_vectors(shape):
+    """Two fixed pseudo-random rank-one probes a (x) b (x) c per tensor shape (weights in [1, 2))."""
+    pv = _PROBES.get(shape)
+    if pv is None:
+        rng = np.random.default_rng(0x51ED0 + 31 * shape[0] + 7 * shape[1] + shape[2])
+        ab = np.stack([np.kron(rng.uniform(1, 2, shape[0]), rng.uniform(1, 2, shape[1])) for _ in range(2)], axis=1)
+        pv = _PROBES[shape] = (ab, rng.uniform(1, 2, (shape[2], 2)))
+    return pv
+
+
 class PovmTensor(np.ndarray):
     """The (S, K, 4^n) POVM tensor as a plain ndarray that also remembers the one-qubit table it is the
     n-fold tensor power of (`factor`, shape (S1, K1, 4)).  The engine uses the factor to contract
     qubit by qubit (qt_set_povm_product); anything derived from the array (slices, arithmetic,
-    np.vstack, np.asarray) is ordinary data without a factor, and a checksum guards against
-    in-place edits of the tensor."""
+    np.vstack, np.asarray) is ordinary data without a factor, and a position-weighted checksum guards
+    against in-place edits of the tensor -- value edits and permutations of outcomes or settings alike."""
 
     def __new__(cls, tensor, factor):
         obj = np.ascontiguousarray(tensor, dtype=np.float64).view(cls)
@@ -39,13 +52,24 @@ class PovmTensor(np.ndarray):
 
     @staticmethod
     def _checksum(arr):
-        flat = np.asarray(arr).ravel()
-        # sum, sum of squares (BLAS dot: no temporary -- the tensor is 64 MB at n = 5) and a strided sample
-        return (arr.shape, float(flat.sum()), float(np.dot(flat, flat)), float(flat[:: max(1, flat.size // 97)].sum()))
+        """(shape, two position-weighted sums, their scale).  sum_{s,k,j} t[s,k,j] a[s] b[k] c[j] with fixed
+        pseudo-random a, b, c: every entry carries its own weight, so moving a value changes the sum -- the
+        plain sum / sum of squares used before is blind to permutations (103 of 108 outcome swaps of
+        'proj-set' went unnoticed).  One GEMM pass over the tensor (64 MB at n = 5: ~5 ms)."""
+        a = np.asarray(arr)
+        ab, c = _probe_vectors(a.shape)
+        v = a.reshape(-1, a.shape[-1]) @ c  # (S*K, 2)
+        return (a.shape, float(v[:, 0] @ ab[:, 0]), float(v[:, 1] @ ab[:, 1]), float(np.abs(v).sum()) + 1e-300)
 
     def valid_factor(self):
         """The one-qubit table, or None when the tensor no longer is its tensor power."""
-        if self.factor is None or self._digest != self._checksum(self):
+        if self.factor is None or self._digest is None:
+            return None
+        now = self._checksum(self)
+        # BLAS may split the sums differently from call to call (thread count): rounding moves them by
+        # ~1e-16 of the scale, an edit or a permutation by many orders more
+        tol = 1e-12 * self._digest[3]
+        if now[0] != self._digest[0] or abs(now[1] - self._digest[1]) > tol or abs(now[2] - self._digest[2]) > tol:
             return None
         return self.factor
 

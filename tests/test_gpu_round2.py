@@ -1,0 +1,106 @@
+"""GPU: the round-1 review items -- the engine leaves the caller's device and stream order alone, the process
+set-up cache follows POVM re-uploads, the POVM guard sees permutations, device sort + quantiles (a16)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_engine_calls_leave_current_device_and_follow_torch_stream(oracle):
+    """ADVICE r1 (high, low): an engine call must not move torch's current device, and device-pointer calls
+    are ordered with the torch work around them without an explicit sync (the engine binds to torch's
+    current stream on its first device-pointer call)."""
+    import torch
+
+    import quantpy_amd as qp
+    from quantpy_amd.engine import Engine
+
+    before = torch.cuda.current_device()
+    eng = Engine(2)  # default device = torch's current device
+    assert eng.device == before
+    a = qp.generate_measurement_matrix("proj-set", 2)
+    eng.set_povm(a, np.full(9, 1000.0))
+    assert torch.cuda.current_device() == before
+    rng = np.random.default_rng(2)
+    g = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
+    rho = g @ g.conj().T
+    rho /= np.trace(rho)
+    np.random.seed(3)
+    counts = np.stack([oracle.sample_counts(np.array(a), oracle.bloch_from_matrix(rho), 1000) for _ in range(4096)])
+    want = eng.lin(counts)
+    cd = torch.from_numpy(counts).cuda()
+    for _ in range(3):
+        # producer (a large fill + copy), engine kernel, consumer: all on torch's current stream, no sync between
+        scratch = torch.zeros((4096, 9, 4), dtype=torch.int64, device="cuda")
+        scratch.copy_(cd)
+        out = torch.full((4096, 4, 4), 7.0, dtype=torch.complex128, device="cuda")
+        eng.lin_dev(scratch, out)
+        total = out.sum()
+        assert np.array_equal(out.cpu().numpy(), want)
+        assert abs(total.item() - want.sum()) < 1e-9
+    assert torch.cuda.current_device() == before
+    eng.close()
+
+
+def test_state_tomography_between_process_estimates_keeps_the_process_setup(oracle):
+    """A -> B -> A on the shared engine: the second process estimate must redo
+    qt_process_setup instead of trusting a key the POVM re-upload invalidated."""
+    import quantpy_amd as qp
+
+    np.random.seed(21)
+    ptm = qp.ProcessTomograph(qp.channel.depolarizing(0.2, 2))
+    ptm.experiment(2000, "proj-set")
+    first = ptm.point_estimate("lifp", cptp=False).choi.matrix
+    stm = qp.StateTomograph(qp.qobj.GHZ(2))
+    stm.experiment(777, "proj-set")  # another shot count: a different POVM key on the same engine
+    stm.point_estimate("lin")
+    again = ptm.point_estimate("lifp", cptp=False).choi.matrix
+    assert np.array_equal(first, again)
+
+
+def test_in_place_permutation_of_tensor_drops_the_factor(oracle):
+    import quantpy_amd as qp
+
+    a = qp.generate_measurement_matrix("proj-set", 2)
+    a[0, [0, 1]] = a[0, [1, 0]]  # outcome swap inside one setting: same sum, same sum of squares
+    assert a.valid_factor() is None
+    eng = qp.get_engine(2)
+    shots = np.full(9, 500.0)
+    eng.set_povm(a, shots)
+    assert not eng.product
+    rng = np.random.default_rng(8)
+    g = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
+    rho = g @ g.conj().T
+    rho /= np.trace(rho)
+    np.random.seed(4)
+    c = oracle.sample_counts(np.array(a), oracle.bloch_from_matrix(rho), 500)
+    assert np.abs(eng.lin(c) - oracle.lin_estimate(c, np.array(a))).max() < 1e-10  # reconstructs with the PERMUTED POVM
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 2000, 100003])
+def test_device_sort_and_quantiles_match_numpy_and_interp1d(n):
+    """a16, interval.py:610-612: dist.sort(); interp1d(linspace(0, 1, n), dist)(conf_levels)."""
+    import torch
+    from scipy.interpolate import interp1d
+
+    import quantpy_amd as qp
+
+    eng = qp.get_engine(1)
+    rng = np.random.default_rng(n)
+    x = np.abs(rng.standard_normal(n)) * 10.0 ** rng.integers(-12, 3, n)
+    x[:: max(1, n // 5)] = 0.0  # exact zeros (hs_dst clamps below 1e-15) and ties
+    levels = np.concatenate(([0.0, 1.0, 0.5, 1e-3, 1 - 1e-3], rng.uniform(0, 1, 40)))
+    if n > 2:
+        levels = np.concatenate((levels, np.linspace(0, 1, n)[[1, n // 2, n - 2]]))  # exactly on grid points
+    srt, q = eng.sort_quantiles(x, levels)
+    assert np.array_equal(srt, np.sort(x))
+    if n > 1:
+        want = interp1d(np.linspace(0, 1, n), np.sort(x))(levels)
+        assert np.array_equal(q, want), np.abs(q - want).max()
+    else:
+        assert np.all(q == x[0])
+    xd = torch.from_numpy(x).cuda()
+    qd = eng.sort_quantiles(xd, levels)
+    assert np.array_equal(xd.cpu().numpy(), srt) and np.array_equal(qd, q)
+    with pytest.raises(ValueError):
+        eng.sort_quantiles(x, [1.5])

@@ -213,6 +213,67 @@ def test_sharded_bootstrap_gather_gloo_world2(tmp_path, n_items):
     assert "rank 0/2 ok" in res.stdout and "rank 1/2 ok" in res.stdout
 
 
+def test_bench_launcher_starts_n_ranks_and_refuses_a_mislabelled_world():
+    """`python bench.py --gpus 2` (the driver's form, no WORLD_SIZE) must start 2 ranks itself -- child
+    torchrun -- and the ranks must see a group of 2; a WORLD_SIZE that contradicts --gpus is an error, not a
+    1-GPU number with rc 0.  (--launch-check forms the group on gloo / CPU and stops before any GPU call.)"""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 2, "rank_sum": 3}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "refusing" in bad.stderr
+
+
+def test_default_device_is_the_ranks_own_gpu(monkeypatch):
+    """every API-level caller used get_engine(n) with device 0.  Without an initialised torch GPU
+    context the engine key follows LOCAL_RANK (QTOMO_DEVICE overrides); an explicit device wins."""
+    from quantpy_amd import engine
+
+    monkeypatch.delenv("QTOMO_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert engine.engine_key(3) == (3, 0)
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert engine.default_device() == 1 and engine.engine_key(3) == (3, 1)
+    assert engine.engine_key(3, device=5) == (3, 5)
+    monkeypatch.setenv("QTOMO_DEVICE", "2")
+    assert engine.engine_key(2) == (2, 2)
+
+
+def test_povm_tensor_guard_sees_permutations(qp, oracle):
+    """sum / sum-of-squares checksums are blind to permutations of exact dyadic entries.  The
+    position-weighted digest must drop the factor for every in-place outcome or setting swap that changes the
+    tensor (host logic only: PovmTensor is built here from the oracle's tensor, no GPU call)."""
+    from quantpy_amd.measurements import _ONE_QUBIT, PovmTensor
+
+    table = _ONE_QUBIT["proj-set"]()
+    full = oracle.measurement_matrix("proj-set", 3)
+    assert PovmTensor(full.copy(), table).valid_factor() is not None
+    changed = 0
+    for s in range(27):
+        for k1 in range(8):
+            for k2 in range(k1 + 1, 8):
+                t = PovmTensor(full.copy(), table)
+                t[s, [k1, k2]] = t[s, [k2, k1]]
+                if not np.array_equal(np.asarray(t), full):
+                    changed += 1
+                    assert t.valid_factor() is None, (s, k1, k2)
+    assert changed == 27 * 28
+    for s in range(26):
+        t = PovmTensor(full.copy(), table)
+        t[[s, s + 1]] = t[[s + 1, s]]
+        assert t.valid_factor() is None, s
+    t = PovmTensor(full.copy(), table)
+    t[3, 2, 5] += 1e-9
+    assert t.valid_factor() is None
+    assert PovmTensor(full.copy(), table)[1:].valid_factor() is None  # derived arrays carry no factor
+
+
 def test_moment_sums_host_math_against_reference_radii(oracle):
     """l2_moments (the reference's twelve stats.py einsums collected into matrix form) with the
     oracle's CPU left inverse must reproduce the reference's MomentInterval radii."""

@@ -44,7 +44,10 @@ enum qt_trial_status {
   QT_TRIAL_NOT_PD = 1,      /* Cholesky pivot <= 0: scipy.linalg.cholesky raises LinAlgError   */
   QT_TRIAL_LINESEARCH = 2,  /* both line searches failed: scipy BFGS warnflag 2                 */
   QT_TRIAL_MAXITER = 3,     /* iteration cap reached: scipy BFGS warnflag 1                     */
-  QT_TRIAL_NAN = 4          /* NaN in value, gradient or parameters: scipy BFGS warnflag 3      */
+  QT_TRIAL_NAN = 4,         /* NaN in value, gradient or parameters: scipy BFGS warnflag 3      */
+  QT_TRIAL_SHOTS = 5        /* the trial's per-setting totals are not proportional to the Ns registered with
+                               qt_set_povm: the reference would weight this trial differently
+                               (state.py:138-141, 194-197); the returned estimate is not meaningful  */
 };
 
 enum qt_flags { QT_HOST_PTR = 0, QT_DEVICE_PTR = 1 };

@@ -622,6 +622,31 @@ def infidelity(a, b):
     return 1 - np.sum(sv) ** 2
 
 
+def trace_dst(a, b):
+    """|Tr sqrtm((A-B)^2)| / 2, zero below 1e-15   (geometry.py:34-38, scipy.linalg.sqrtm as there)."""
+    diff = a - b
+    dist = abs(np.trace(la.sqrtm(diff @ diff))) / 2
+    return 0 if dist < 1e-15 else dist
+
+
+def if_dst(a, b):
+    """1 - |Tr sqrtm(sqrtm(A) B sqrtm(A))|^2, zero below 1e-15   (geometry.py:52-56).  The reference's own
+    expression, scipy.linalg.sqrtm included: on singular arguments sqrtm is only ~1e-8 accurate, which is why the
+    parity harness measures fidelity with `infidelity` above; this function pins what `if_dst` itself returns."""
+    root = la.sqrtm(a)
+    dist = 1 - np.abs(np.trace(la.sqrtm(root @ b @ root)) ** 2)
+    return 0 if dist < 1e-15 else dist
+
+
+def warm_start_stack(povm_old, results_old, povm_new, results_new):
+    """experiment(..., warm_start=True)   (state.py:116-124): the POVM tensors are stacked with weights
+    total-old-shots : total-new-shots, the counts are stacked; n_measurements follows from the results setter
+    (state.py:138-141)."""
+    n_old, n_new = np.sum(results_old.sum(-1)), np.sum(results_new.sum(-1))
+    povm = np.vstack((povm_old * n_old, povm_new * n_new)) / (n_old + n_new)
+    return povm, np.vstack((results_old, results_new))
+
+
 # --------------------------------------------------------------------------------------
 # a16: bootstrap                                    (reference interval.py:583-612)
 # --------------------------------------------------------------------------------------
@@ -719,6 +744,49 @@ def lifp_estimate(counts, povm_matrix, in_states, return_oper=False):
     freq = np.hstack([c.flatten() / c.sum() for c in counts])
     choi = vec2mat(inv @ freq)
     return (choi, oper, inv) if return_oper else choi
+
+
+def decompose_single_entries(in_states):
+    """process.py:75-80 with basis.py:20-35: coordinates of the d^2 single-entry matrices E_ij in the input basis,
+    conj(solve(Gram, rhs)), Gram_ab = Tr(rho_a rho_b^dagger), rhs_a = Tr(rho_a E^dagger)."""
+    dim = len(in_states)
+    d = in_states[0].shape[0]
+    gram = np.array([[np.trace(a @ b.conj().T) for b in in_states] for a in in_states], dtype=np.complex128)
+    rows = []
+    for i in range(d):
+        for j in range(d):
+            e = np.zeros((d, d))
+            e[i, j] = 1
+            rhs = np.array([np.trace(a @ e.conj().T) for a in in_states], dtype=np.complex128)
+            rows.append(np.conj(la.solve(gram, rhs)))
+    assert len(rows) == dim
+    return np.array(rows)
+
+
+def choi_is_cptp(choi, n, atol=1e-5):
+    """channel.py:144-157: Tr_out C = I and min(eig, 0) = 0 within atol (eigenvalues through scipy.linalg.eig of
+    the general matrix, real parts, as Qobj.eig does for a non-Hermitian-checked matrix)."""
+    d = 2**n
+    reduced = np.einsum("iaja->ij", choi.reshape(d, d, d, d))
+    tp = np.allclose(reduced, np.eye(d), atol=atol)
+    cp = np.allclose(np.minimum(np.real(la.eigvals(choi)), 0), 0, atol=atol)
+    return tp and cp
+
+
+def states_estimate(counts, povm_matrix, in_states, n, cptp=True):
+    """'states' process estimator (process.py:316-327): output states by 'lin', C = sum_e E_e (x) sum_s c_es rho_out_s,
+    CPTP projection only when C fails is_cptp."""
+    outs = [lin_estimate(c, povm_matrix) for c in counts]
+    coeff = decompose_single_entries(in_states)
+    d = in_states[0].shape[0]
+    choi = np.zeros((d * d, d * d), dtype=np.complex128)
+    for row in coeff:
+        unit = sum(c * s for c, s in zip(row, in_states))
+        image = sum(c * o for c, o in zip(row, outs))
+        choi += np.kron(unit, image)
+    if cptp and not choi_is_cptp(choi, n):
+        choi = cptp_projection(choi, n)
+    return choi
 
 
 def tp_projection_vec(v, n):

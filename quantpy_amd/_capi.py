@@ -15,7 +15,7 @@ QT_STREAM_LEGACY = 1  # qt_set_stream: the legacy default ("null") stream
 
 # status codes (include/qtomo.h)
 QT_ERR_ARG, QT_ERR_STATE, QT_ERR_HIP, QT_ERR_SINGULAR, QT_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
-TRIAL_OK, TRIAL_NOT_PD, TRIAL_LINESEARCH, TRIAL_MAXITER, TRIAL_NAN = 0, 1, 2, 3, 4
+TRIAL_OK, TRIAL_NOT_PD, TRIAL_LINESEARCH, TRIAL_MAXITER, TRIAL_NAN, TRIAL_SHOTS = 0, 1, 2, 3, 4, 5
 
 _c_int = ctypes.c_int
 _c_dbl = ctypes.c_double

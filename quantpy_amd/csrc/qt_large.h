@@ -67,6 +67,7 @@ struct Large {
     ProductView pr;
     const int64_t* counts;  // this trial's counts [M]
     double tot;             // sum of counts
+    bool shots_ok;          // per-setting totals proportional to the registered shots (PovmView::Ns)
     int xm, zm, ny;
     int pi, pj, pkind;
     __device__ __forceinline__ cd* L() const { return reinterpret_cast<cd*>(sm + oL); }
@@ -148,6 +149,16 @@ struct Large {
     if (counts)
       for (int m = c.t; m < c.M; m += NT) part += (double)counts[m];
     c.tot = bsum(c, part);  // (barriers inside also publish the tables)
+    // shots check (state.py:138-141, 194-197): thread s sums the K outcomes of setting s (L2 hits: just read)
+    double bad = 0.0;
+    if (counts && pv.Ns) {
+      for (int s = c.t; s < pv.S; s += NT) {
+        double t = 0.0;
+        for (int k = 0; k < pv.K; ++k) t += (double)counts[s * pv.K + k];
+        if (!shots_match(t, c.tot, pv.Ns[s], pv.ns_tot)) bad = 1.0;
+      }
+    }
+    c.shots_ok = !(counts && pv.Ns) || !(bmax(c, bad) > 0.0);
   }
   // frequency of R-order row o (state.py:193, :227)
   __device__ __forceinline__ static double freq(const Ctx& c, int o) { return (double)c.counts[c.pr.rmap[o]] / c.tot; }
@@ -473,7 +484,7 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_lin_large(PovmView pv, const 
   out[0] = r.re;
   out[1] = r.im;
   if (bloch_out) bloch_out[(size_t)b * S::D + c.t] = bl;
-  if (status && c.t == 0) status[b] = (r.re == r.re) ? 0 : 4;
+  if (status && c.t == 0) status[b] = !c.shots_ok ? 5 : (r.re == r.re) ? 0 : 4;
 }
 
 template <int NQ>
@@ -584,8 +595,8 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
   }
   QT_STAMP(8);
   double fk = 0.0, gk = 0.0;
-  int kiter = 0, nfev = 0, status = ok ? 0 : 1;
-  bool active = ok != 0;
+  int kiter = 0, nfev = 0, status = !c.shots_ok ? 5 : (ok ? 0 : 1);
+  bool active = ok != 0 && c.shots_ok;
   if (active) {
     S::nll_grad(c, xk, fk, gk);
     QT_STAMP(9);
@@ -664,7 +675,7 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
     pk = -q;
     ls.start(fk, old_old, S::bsum(c, gk * pk), &stp);
   }
-  if (status == 0 && ok) {
+  if (status == 0 && ok) {  // (status 5 trials never evaluated: fk = 0, the start point is returned)
     const double gn = S::bmax(c, fabs(gk));
     const double xn = S::bmax(c, fabs(xk));
     if (kiter >= max_iter) status = 3;

@@ -9,20 +9,21 @@
 namespace qt {
 
 // ---- a1: routines.py:14-19 ----------------------------------------------------------------
-// out[k][r][c] = (c == r ^ x(k)) ? (-i)^ny(k) (-1)^popc(r & z(k)) : 0, one thread per element.
-__global__ void k_pauli_basis(int nq, double* __restrict__ out) {
-  const int d = 1 << nq;
-  const size_t total = (size_t)d * d * d * d;
+// out[k][r][c] = (c == r ^ x(k)) ? (-i)^ny(k) (-1)^popc(r & z(k)) : 0.  One thread per complex element, one
+// 16-byte store per lane (a wavefront writes 1 KB contiguous); d is a power of two, so the three indices are
+// shifts and masks of the flat element number (the first version divided 64-bit numbers by a run-time d).
+__global__ void __launch_bounds__(256) k_pauli_basis(int nq, double* __restrict__ out) {
+  const unsigned d = 1u << nq, dm = d - 1;
+  const size_t total = (size_t)1 << (4 * nq);
+  double2* o2 = reinterpret_cast<double2*>(out);
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(e % d);
-    const int r = (int)((e / d) % d);
-    const int k = (int)(e / ((size_t)d * d));
-    int xm = 0, zm = 0, ny = 0;
+    const unsigned c = (unsigned)e & dm, r = (unsigned)(e >> nq) & dm, k = (unsigned)(e >> (2 * nq));
+    unsigned xm = 0, zm = 0, ny = 0;
     for (int b = 0; b < nq; ++b) {
-      const int dig = (k >> (2 * b)) & 3;
-      if (dig == 1 || dig == 2) xm |= 1 << b;
-      if (dig == 2 || dig == 3) zm |= 1 << b;
-      if (dig == 2) ++ny;
+      const unsigned dig = (k >> (2 * b)) & 3;
+      xm |= (unsigned)(dig == 1 || dig == 2) << b;
+      zm |= (unsigned)(dig >= 2) << b;
+      ny += dig == 2;
     }
     double re = 0.0, im = 0.0;
     if (c == (r ^ xm)) {
@@ -34,64 +35,94 @@ __global__ void k_pauli_basis(int nq, double* __restrict__ out) {
         default: im = sg; break;
       }
     }
-    out[2 * e] = re;
-    out[2 * e + 1] = im;
+    o2[e] = double2{re, im};
   }
 }
 
 // ---- a2: measurements.py:88-93 --------------------------------------------------------------
 // out[s][k][j] = prod_q povm1[s_q][k_q][j_q], digits most-significant first, multiplied left to
-// right exactly as repeated np.kron does ((a*b)*c...).
-__global__ void k_povm_kron(int nq, const double* __restrict__ p1, int S1, int K1, double* __restrict__ out) {
-  size_t S = 1, K = 1, D = 1;
-  for (int q = 0; q < nq; ++q) {
-    S *= S1;
-    K *= K1;
-    D *= 4;
-  }
-  const size_t total = S * K * D;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    size_t j = e % D, k = (e / D) % K, s = e / (D * K);
-    // peel digits from the most significant qubit
-    size_t sdiv = S / S1, kdiv = K / K1, jdiv = D / 4;
+// right exactly as repeated np.kron does ((a*b)*c...): bit-identical entries.
+// HBM-write bound (8 S K D bytes, 63.7 MB at n = 5).  A lane produces TWO neighbouring entries (they share every
+// factor but the last) and stores them as one 16-byte word, so a wavefront instruction writes 1 KB contiguous.
+// No division anywhere: the row's n digits r_q = s_q K1 + k_q come packed (8 bits each) from a table the host
+// builds once per (S1, K1, n), the Pauli digits j_q are bit fields of the column, the one-qubit table sits in LDS.
+__global__ void __launch_bounds__(256) k_povm_kron(int nq, const double* __restrict__ p1, int R1,
+                                                   const unsigned long long* __restrict__ rowdig, size_t total,
+                                                   double* __restrict__ out) {
+  __shared__ double tab[256 * 4];
+  for (int e = threadIdx.x; e < R1 * 4; e += blockDim.x) tab[e] = p1[e];
+  __syncthreads();
+  const unsigned dmask = (1u << (2 * nq)) - 1;
+  double2* o2 = reinterpret_cast<double2*>(out);
+  const size_t npairs = total >> 1;
+  for (size_t pidx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; pidx < npairs; pidx += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = pidx << 1;
+    const unsigned j = (unsigned)e & dmask;
+    const unsigned long long dig = rowdig[e >> (2 * nq)];
     double v = 0.0;
-    for (int q = 0; q < nq; ++q) {
-      const int sq = (int)(s / sdiv), kq = (int)(k / kdiv), jq = (int)(j / jdiv);
-      s %= sdiv;
-      k %= kdiv;
-      j %= jdiv;
-      const double f = p1[((size_t)sq * K1 + kq) * 4 + jq];
+    for (int q = 0; q + 1 < nq; ++q) {
+      const unsigned r = (unsigned)(dig >> (8 * q)) & 255u, jq = (j >> (2 * (nq - 1 - q))) & 3u;
+      const double f = tab[r * 4 + jq];
       v = (q == 0) ? f : v * f;
-      if (q + 1 < nq) {
-        sdiv /= S1;
-        kdiv /= K1;
-        jdiv /= 4;
-      }
     }
-    out[e] = v;
+    const unsigned rl = (unsigned)(dig >> (8 * (nq - 1))) & 255u, jl = j & 3u;  // jl is 0 or 2
+    const double f0 = tab[rl * 4 + jl], f1 = tab[rl * 4 + jl + 1];
+    o2[pidx] = (nq == 1) ? double2{f0, f1} : double2{v * f0, v * f1};
   }
 }
 
-// ---- state.py:194-197: A' = A * Ns[s] / sum(Ns), plus its transpose ---------------------------
-__global__ void k_weight_povm(const double* __restrict__ A, const double* __restrict__ Ns, int S, int K, int D,
-                              double* __restrict__ Aw, double* __restrict__ AwT) {
-  double tot = 0.0;
-  for (int s = 0; s < S; ++s) tot += Ns[s];
-  const size_t M = (size_t)S * K;
-  const size_t total = M * D;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const size_t m = e / D, k = e % D;
-    const double v = A[e] * Ns[m / K] / tot;
-    Aw[e] = v;
-    AwT[k * M + m] = v;
+// ---- state.py:194-197 and the transposes the dense kernels read: from A [M][D] (row m = s K + k) produce
+// A^T [D][M], A' = A * Ns[s] / sum(Ns) [M][D] and A'^T [D][M] in ONE pass: a 64 x 64 tile goes through LDS
+// (pitch 65: the transposed read is conflict-free), so every global access is a full 512-byte row segment.
+// `tot` = sum(Ns), summed once on the host (the first version had every thread re-add Ns[0..S)).
+__global__ void __launch_bounds__(256) k_povm_setup(const double* __restrict__ A, const double* __restrict__ Ns, double tot,
+                                                    int K, int M, int D, double* __restrict__ AT, double* __restrict__ Aw,
+                                                    double* __restrict__ AwT) {
+  __shared__ double ta[64][65], tw[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  for (int r = ty; r < 64; r += 4) {
+    const int m = m0 + r, k = k0 + tx;
+    if (m < M && k < D) {
+      const double a = A[(size_t)m * D + k];
+      const double w = a * Ns[m / K] / tot;
+      ta[r][tx] = a;
+      tw[r][tx] = w;
+      Aw[(size_t)m * D + k] = w;
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int k = k0 + r, m = m0 + tx;
+    if (k < D && m < M) {
+      AT[(size_t)k * M + m] = ta[tx][r];
+      AwT[(size_t)k * M + m] = tw[tx][r];
+    }
   }
 }
 
-__global__ void k_transpose(const double* __restrict__ in, int R, int C, double* __restrict__ out) {
-  const size_t total = (size_t)R * C;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = e / C, c = e % C;
-    out[c * R + r] = in[e];
+// out[C][R] = in[R][C]^T through an LDS tile (64 x 64 real, 32 x 32 complex; odd pitch: the transposed read is
+// conflict-free).  W = 1 real, W = 2 complex (interleaved).
+template <int W>
+__global__ void __launch_bounds__(256) k_transpose_tiled(const double* __restrict__ in, int R, int C, double* __restrict__ out) {
+  constexpr int TS = 64 / W, STEP = 256 / TS;
+  __shared__ double tile[TS][TS * W + 1];
+  const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
+  const int r0 = blockIdx.y * TS, c0 = blockIdx.x * TS;
+  for (int r = ty; r < TS; r += STEP) {
+    const int rr = r0 + r, cc = c0 + tx;
+    if (rr < R && cc < C) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) tile[r][tx * W + w] = in[((size_t)rr * C + cc) * W + w];
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < TS; r += STEP) {
+    const int cc = c0 + r, rr = r0 + tx;
+    if (cc < C && rr < R) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) out[((size_t)cc * R + rr) * W + w] = tile[tx][r * W + w];
+    }
   }
 }
 

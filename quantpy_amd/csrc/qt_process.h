@@ -52,15 +52,6 @@ __global__ void k_lifp_rows(int d, int M, const double* __restrict__ in_states, 
   }
 }
 
-__global__ void k_transpose_c(const double* __restrict__ in, int R, int C, double* __restrict__ out) {
-  const size_t total = (size_t)R * C;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = e / C, c = e % C;
-    out[2 * (c * R + r)] = in[2 * e];
-    out[2 * (c * R + r) + 1] = in[2 * e + 1];
-  }
-}
-
 template <int NT>
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
   v = gsum<64>(v);  // DPP: 8 vector instructions instead of 12 ds_bpermute round trips

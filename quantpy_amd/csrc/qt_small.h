@@ -278,7 +278,20 @@ struct PovmView {
   int M;
   ProductView pr;
   double jtol2 = 1e-28;  // Jacobi stops when off-diagonal norm^2 <= jtol2 * Frobenius norm^2
+  // shots per setting as registered with qt_set_povm (the weights N_s / sum N inside A' come from these);
+  // every trial's own per-setting totals must be proportional to them (state.py:138-141, 194-197: the
+  // reference takes the weights from the trial's results) or the trial is flagged QT_TRIAL_SHOTS
+  const double* Ns = nullptr;  // [S]
+  int S = 0, K = 0;
+  double ns_tot = 0.0;
 };
+
+// t_s / total == N_s / ns_tot, compared as cross products of integer-valued doubles (exact below 2^53; a few
+// ulp of slack beyond that -- one stray count out of N_s < 1e14 is still seen)
+__device__ __forceinline__ bool shots_match(double t_s, double total, double n_s, double ns_tot) {
+  const double a = t_s * ns_tot, b = n_s * total;
+  return fabs(a - b) <= 2e-15 * fabs(b);
+}
 
 template <int NQ, bool ALDS>
 struct Small {
@@ -533,10 +546,11 @@ struct Small {
   // of that set-up; up to 4 values per lane are held in registers until load_freq picks them up.
   struct Prefetch {
     int64_t v[4];
+    double ns;  // N_s of setting s = lane (the shots check of load_freq)
     bool ok;
   };
-  __device__ __forceinline__ static void prefetch_counts(Prefetch& pf, const int64_t* counts, int M) {
-    const int l = (threadIdx.x & 63) % G;
+  __device__ __forceinline__ static void prefetch_counts(Prefetch& pf, const int64_t* counts, const PovmView& pv) {
+    const int l = (threadIdx.x & 63) % G, M = pv.M;
     pf.ok = M <= 4 * G;
     if (pf.ok) {
 #pragma unroll
@@ -545,8 +559,10 @@ struct Small {
         pf.v[q] = counts[m < M ? m : M - 1];
       }
     }
+    pf.ns = pv.Ns ? pv.Ns[l < pv.S ? l : pv.S - 1] : 0.0;
   }
-  __device__ static void load_freq(const Ctx& c, const int64_t* counts, const Prefetch* pf = nullptr) {
+  // Returns false when the trial's per-setting totals are not proportional to the registered shots.
+  __device__ static bool load_freq(const Ctx& c, const int64_t* counts, const Prefetch* pf = nullptr) {
     // one coalesced pass over the counts: values parked in rbuf
     double part = 0.0;
     double* raw = c.rbuf();
@@ -573,14 +589,28 @@ struct Small {
         c.tabP()[e] = c.pv.pr.P1T[e];
       }
     }
-    const double inv = 1.0 / gsum<G>(part);
+    const double total = gsum<G>(part);
+    const double inv = 1.0 / total;
     wave_sync();
     if (c.prod()) {
       for (int m = c.l; m < c.M; m += G) c.freq()[m] = raw[c.trmap[m]] * inv;
     } else {
       for (int m = c.l; m < c.M; m += G) c.freq()[m] = raw[m] * inv;
     }
+    // shots check: lane s sums the K outcomes of setting s (raw is in the caller's (S, K) order)
+    double bad = 0.0;
+    if (c.pv.Ns) {
+      const int K = c.pv.K;
+      for (int s = c.l; s < c.pv.S; s += G) {
+        double t = 0.0;
+        for (int k = 0; k < K; ++k) t += raw[s * K + k];
+        const double ns = (pf && s == c.l) ? pf->ns : c.pv.Ns[s];
+        if (!shots_match(t, total, ns, c.pv.ns_tot)) bad = 1.0;
+      }
+    }
+    const bool shots_ok = !(gmax<G>(bad) > 0.0);
     wave_sync();
+    return shots_ok;
   }
 
   // ---- factorised contractions for product POVMs -----------------------------------------------
@@ -1115,11 +1145,11 @@ __global__ void __launch_bounds__(256) k_lin_batch(PovmView pv, const int64_t* _
   const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;  // padding groups recompute the last trial; nothing is stored
   typename S::Prefetch pf;
-  S::prefetch_counts(pf, counts + (size_t)bb * pv.M, pv.M);
+  S::prefetch_counts(pf, counts + (size_t)bb * pv.M, pv);
   S::make_ctx(c, smem, pv);
   QT_STAMP(0);
   S::load_image(c, pv.PinvT);
-  S::load_freq(c, counts + (size_t)bb * pv.M, &pf);
+  const bool shots_ok = S::load_freq(c, counts + (size_t)bb * pv.M, &pf);
   QT_STAMP(1);
   double bl;
   cd r = S::lin_invert(c, bl);
@@ -1131,7 +1161,7 @@ __global__ void __launch_bounds__(256) k_lin_batch(PovmView pv, const int64_t* _
     out[0] = r.re;
     out[1] = r.im;
     if (bloch_out) bloch_out[(size_t)b * S::D + c.l] = bl;
-    if (status && c.l == 0) status[b] = (r.re == r.re) ? 0 : 4;
+    if (status && c.l == 0) status[b] = !shots_ok ? 5 : (r.re == r.re) ? 0 : 4;
   }
 }
 
@@ -1217,9 +1247,9 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
   const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;
   typename S::Prefetch pf;
-  S::prefetch_counts(pf, counts + (size_t)bb * pv.M, pv.M);
+  S::prefetch_counts(pf, counts + (size_t)bb * pv.M, pv);
   S::make_ctx(c, smem, pv);
-  S::load_freq(c, counts + (size_t)bb * pv.M, &pf);
+  const bool shots_ok = S::load_freq(c, counts + (size_t)bb * pv.M, &pf);
   int ok;
   double xk;
   typename S::StartPoint sp;
@@ -1239,9 +1269,10 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
   cd rho_l;  // L L^dagger / Tr at x_k: what the trial returns if BFGS does not move
   S::nll_grad(c, xk, fk, gk, &rho_l, true, &sp);
   const double gnorm = gmax<G>(fabs(gk));
-  const bool iterate = ok && (gnorm > gtol) && (0 < max_iter);
+  const bool iterate = shots_ok && ok && (gnorm > gtol) && (0 < max_iter);
   int status = 0;
-  if (!ok) status = 1;
+  if (!shots_ok) status = 5;
+  else if (!ok) status = 1;
   else if (!iterate) {
     const double xn = gmax<G>(fabs(xk));
     if (0 >= max_iter) status = 3;
@@ -1445,10 +1476,10 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
   const int b = S::trial_index(B, &live);
   const int bb = live ? b : B - 1;
   typename S::Prefetch pf;
-  S::prefetch_counts(pf, counts + (size_t)bb * pv.M, pv.M);
+  S::prefetch_counts(pf, counts + (size_t)bb * pv.M, pv);
   S::make_ctx(c, smem, pv);
   QT_STAMP(0);
-  S::load_freq(c, counts + (size_t)bb * pv.M, &pf);
+  const bool shots_ok = S::load_freq(c, counts + (size_t)bb * pv.M, &pf);
   QT_STAMP(1);
   int ok;
   double xk;
@@ -1472,10 +1503,11 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
   S::nll_grad(c, xk, fk, gk, &rho_l, true, &sp);
   const double gnorm = gmax<G>(fabs(gk));
   QT_STAMP(9);
-  const bool iterate = live && ok && (gnorm > gtol) && (0 < max_iter);
+  const bool iterate = live && shots_ok && ok && (gnorm > gtol) && (0 < max_iter);
   if (!iterate) {
     int status = 0;
-    if (!ok) status = 1;
+    if (!shots_ok) status = 5;
+    else if (!ok) status = 1;
     else {
       const double xn = gmax<G>(fabs(xk));
       if (0 >= max_iter) status = 3;

@@ -67,10 +67,15 @@ struct qt_handle {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // POVM cache
-  bool povm_set = false, pinv_ready = false;
+  // POVM cache.  The dense operands A, A^T, A', A'^T ([M][D] each: 64 MB at n = 5) exist when `dense_ready`;
+  // a product POVM at n >= 4 never reads them and builds them only on demand (ensure_dense), likewise the dense
+  // left inverse (`pinv_ready`, compute_dense_pinv).
+  bool povm_set = false, dense_ready = false, a_loaded = false, pinv_ready = false;
   int S = 0, K = 0, M = 0;
   DevBuf A, AT, Aw, AwT, Pinv, PinvT, Ns, aug, info;
+  // packed row digits of the Kronecker assembly (k_povm_kron), cached per (S1, K1)
+  DevBuf kron_dig;
+  int kron_S1 = 0, kron_K1 = 0;
   // product-POVM (Kronecker) description, valid when prod.enabled
   DevBuf pr_T, pr_P1, pr_P1T, pr_wrow, pr_rmap, pr_fwd, pr_bwd, pr_aug;
   qt::ProductView prod{};
@@ -86,7 +91,10 @@ struct qt_handle {
   qt::ProcessState proc;
   bool proc_set = false;
 
-  qt::PovmView view() const { return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod, jtol2}; }
+  double ns_tot = 0.0;  // sum of the registered shots per setting
+  qt::PovmView view() const {
+    return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod, jtol2, Ns.as<double>(), S, K, ns_tot};
+  }
   // Jacobi stopping rule off^2 <= jtol2 * ||A||_F^2.  Measured on the C2 batch: the last sweep takes off^2
   // from > 1e-9 to < 1e-28 in one go, so no looser threshold saves a sweep without costing accuracy.
   double jtol2 = 1e-28;
@@ -257,6 +265,12 @@ void launch_gauss_jordan(qt_handle_t* h, int n, double* aug, int* info) {
   }
 }
 
+template <int W>
+void launch_transpose(qt_handle_t* h, const double* in, int R, int C, double* out) {
+  constexpr int TS = 64 / W;
+  hipLaunchKernelGGL(qt::k_transpose_tiled<W>, dim3((C + TS - 1) / TS, (R + TS - 1) / TS), dim3(256), 0, h->stream, in, R, C, out);
+}
+
 int need_povm(qt_handle_t* h) {
   if (!h->povm_set) return fail(QT_ERR_STATE, "qt_set_povm has not been called on this handle");
   return 0;
@@ -317,7 +331,7 @@ void qt_destroy(qt_handle_t* h) {
   DeviceScope scope(h->device);
   (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->pr_T, &h->pr_P1, &h->pr_P1T, &h->pr_wrow, &h->pr_rmap, &h->pr_fwd, &h->pr_bwd, &h->pr_aug}) b->release();
-  for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->in0, &h->in1,
+  for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->kron_dig, &h->in0, &h->in1,
                     &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug, &h->ws_x, &h->ws_g, &h->ws_f,
                     &h->ws_act, &h->hess, &h->sort_alt, &h->sort_tmp})
     b->release();
@@ -376,6 +390,48 @@ int qt_pauli_basis(qt_handle_t* h, double* out, int flags) {
   return finish(h, flags);
 }
 
+// Row digits for k_povm_kron: row = s K + k with s = sum_q s_q S1^(n-1-q), k likewise; byte q = s_q K1 + k_q.
+static int ensure_kron_digits(qt_handle_t* h, int S1, int K1) {
+  if (h->kron_S1 == S1 && h->kron_K1 == K1 && h->kron_dig.p) return 0;
+  const int n = h->nq;
+  long long S = 1, K = 1;
+  for (int q = 0; q < n; ++q) {
+    S *= S1;
+    K *= K1;
+  }
+  std::vector<unsigned long long> dig((size_t)(S * K));
+  for (long long s = 0; s < S; ++s)
+    for (long long k = 0; k < K; ++k) {
+      unsigned long long pack = 0;
+      long long sr = s, kr = k;
+      for (int q = n - 1; q >= 0; --q) {
+        pack |= (unsigned long long)((sr % S1) * K1 + (kr % K1)) << (8 * q);
+        sr /= S1;
+        kr /= K1;
+      }
+      dig[(size_t)(s * K + k)] = pack;
+    }
+  h->kron_S1 = h->kron_K1 = 0;
+  HIPCHK(h->kron_dig.ensure(dig.size() * sizeof(unsigned long long)));
+  HIPCHK(hipMemcpyAsync(h->kron_dig.p, dig.data(), dig.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));  // `dig` goes out of scope
+  h->kron_S1 = S1;
+  h->kron_K1 = K1;
+  return 0;
+}
+
+static int launch_povm_kron(qt_handle_t* h, const double* dtable, int S1, int K1, double* dout) {
+  if (S1 * K1 > 255) return fail(QT_ERR_UNSUPPORTED, "one-qubit table with %d rows (> 255)", S1 * K1);
+  if (int r = ensure_kron_digits(h, S1, K1)) return r;
+  size_t total = (size_t)h->D;
+  for (int q = 0; q < h->nq; ++q) total *= (size_t)S1 * K1;
+  if ((total >> (2 * h->nq)) > ((size_t)1 << 31)) return fail(QT_ERR_UNSUPPORTED, "POVM tensor too large");
+  // >> 256 workgroups, each lane a 16-byte store per pass
+  hipLaunchKernelGGL(qt::k_povm_kron, dim3(grid_for(total / 2, 256, 4096)), dim3(256), 0, h->stream, h->nq, dtable, S1 * K1,
+                     h->kron_dig.as<unsigned long long>(), total, dout);
+  return 0;
+}
+
 int qt_povm_kron(qt_handle_t* h, const double* povm1, int S1, int K1, double* out, int flags) {
   QT_ENTER(h);
   if (!povm1 || !out || S1 < 1 || K1 < 1) return fail(QT_ERR_ARG, "bad povm_kron arguments");
@@ -389,14 +445,41 @@ int qt_povm_kron(qt_handle_t* h, const double* povm1, int S1, int K1, double* ou
   double* dout;
   if (int r = stage_in(h, h->in0, povm1, (size_t)S1 * K1 * 4, flags, &din)) return r;
   if (int r = stage_out(h, h->out0, out, n, flags, &dout)) return r;
-  hipLaunchKernelGGL(qt::k_povm_kron, dim3(grid_for(n)), dim3(256), 0, h->stream, h->nq, din, S1, K1, dout);
+  if (int r = launch_povm_kron(h, din, S1, K1, dout)) return r;
   if (int r = fetch_out(h, dout, out, n, flags)) return r;
   return finish(h, flags);
 }
 
+// Dense operands A ([M][D]; the Kronecker power of the table for a product POVM), A^T, A', A'^T -- built when first
+// needed: Born kernel / dense estimators at n <= 3, process set-up, the dense left inverse.
+static int ensure_dense(qt_handle_t* h) {
+  if (h->dense_ready) return 0;
+  const size_t bytes = (size_t)h->M * h->D * sizeof(double);
+  HIPCHK(h->A.ensure(bytes));
+  HIPCHK(h->AT.ensure(bytes));
+  HIPCHK(h->Aw.ensure(bytes));
+  HIPCHK(h->AwT.ensure(bytes));
+  if (!h->a_loaded) {
+    if (!h->pr_T.p || h->kron_S1 * h->kron_K1 == 0) return fail(QT_ERR_STATE, "no POVM tensor to build the dense operands from");
+    if (int r = launch_povm_kron(h, h->pr_T.as<double>(), h->kron_S1, h->kron_K1, h->A.as<double>())) return r;
+    h->a_loaded = true;
+  }
+  hipLaunchKernelGGL(qt::k_povm_setup, dim3((h->D + 63) / 64, (h->M + 63) / 64), dim3(256), 0, h->stream, h->A.as<double>(),
+                     h->Ns.as<double>(), h->ns_tot, h->K, h->M, h->D, h->AT.as<double>(), h->Aw.as<double>(),
+                     h->AwT.as<double>());
+  HIPCHK(hipGetLastError());
+  h->dense_ready = true;
+  return 0;
+}
+
 // Dense left inverse inv(A'^T A') A'^T of the cached weighted POVM (Gram GEMM, pivoted Gauss-Jordan, GEMM).
 static int compute_dense_pinv(qt_handle_t* h) {
+  if (int r = ensure_dense(h)) return r;
   const int D = h->D, M = h->M;
+  const size_t bytes = (size_t)M * D * sizeof(double);
+  HIPCHK(h->Pinv.ensure(bytes));
+  HIPCHK(h->PinvT.ensure(bytes));
+  HIPCHK(h->aug.ensure((size_t)D * 2 * D * sizeof(double)));
   double *dAw = h->Aw.as<double>(), *dAwT = h->AwT.as<double>();
   double *dP = h->Pinv.as<double>(), *dPT = h->PinvT.as<double>(), *aug = h->aug.as<double>();
   dim3 gg((D + 15) / 16, (D + 15) / 16);
@@ -404,7 +487,7 @@ static int compute_dense_pinv(qt_handle_t* h) {
   launch_gauss_jordan<0>(h, D, aug, h->info.as<int>());
   dim3 gp((M + 15) / 16, (D + 15) / 16);
   hipLaunchKernelGGL(qt::k_gemm<0>, gp, dim3(64), 0, h->stream, D, M, D, aug + D, 2 * D, 0, dAwT, M, 0, dP, M);
-  hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for((size_t)M * D)), dim3(256), 0, h->stream, dP, D, M, dPT);
+  launch_transpose<1>(h, dP, D, M, dPT);
   int info = 0;
   HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipGetLastError());
@@ -414,45 +497,18 @@ static int compute_dense_pinv(qt_handle_t* h) {
   return 0;
 }
 
-// Shared tail of qt_set_povm / qt_set_povm_product: h->A ([M][D]) and h->Ns ([S]) are on the device.
-// `dense_pinv`: build the dense left inverse now (a factorised POVM with equal shots never reads it:
-// it is then built on demand by qt_get_left_inverse -- at n = 5 that is 0.75 s of set-up saved).
-static int finish_set_povm(qt_handle_t* h, int S, int K, bool dense_pinv) {
-  const int D = h->D;
+// Start of qt_set_povm / qt_set_povm_product: forget the previous POVM, record the shape.
+static int begin_povm(qt_handle_t* h, int S, int K) {
   const size_t M = (size_t)S * K;
-  double *dA = h->A.as<double>(), *dAT = h->AT.as<double>(), *dAw = h->Aw.as<double>(), *dAwT = h->AwT.as<double>();
-  hipLaunchKernelGGL(qt::k_transpose, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dA, (int)M, D, dAT);
-  hipLaunchKernelGGL(qt::k_weight_povm, dim3(grid_for(M * D)), dim3(256), 0, h->stream, dA, h->Ns.as<double>(), S, K, D,
-                     dAw, dAwT);
+  if (M < (size_t)h->D) return fail(QT_ERR_SINGULAR, "POVM has %zu rows < D = %d: not informationally complete", M, h->D);
+  h->povm_set = false;
+  h->proc_set = false;
+  h->dense_ready = h->a_loaded = h->pinv_ready = false;
+  h->prod = qt::ProductView{};
   h->S = S;
   h->K = K;
   h->M = (int)M;
-  h->pinv_ready = false;
-  if (dense_pinv) {
-    if (int r = compute_dense_pinv(h)) return r;
-  } else {
-    HIPCHK(hipGetLastError());
-  }
-  h->povm_set = true;
-  return 0;
-}
-
-static int alloc_povm(qt_handle_t* h, int S, int K) {
-  const int D = h->D;
-  const size_t M = (size_t)S * K;
-  if (M < (size_t)D) return fail(QT_ERR_SINGULAR, "POVM has %zu rows < D = %d: not informationally complete", M, D);
-  h->povm_set = false;
-  h->proc_set = false;
-  h->prod = qt::ProductView{};
-  const size_t bytes = M * D * sizeof(double);
-  HIPCHK(h->A.ensure(bytes));
-  HIPCHK(h->AT.ensure(bytes));
-  HIPCHK(h->Aw.ensure(bytes));
-  HIPCHK(h->AwT.ensure(bytes));
-  HIPCHK(h->Pinv.ensure(bytes));
-  HIPCHK(h->PinvT.ensure(bytes));
   HIPCHK(h->Ns.ensure(S * sizeof(double)));
-  HIPCHK(h->aug.ensure((size_t)D * 2 * D * sizeof(double)));
   HIPCHK(h->info.ensure(sizeof(int)));
   return 0;
 }
@@ -460,17 +516,28 @@ static int alloc_povm(qt_handle_t* h, int S, int K) {
 int qt_set_povm(qt_handle_t* h, const double* A, int S, int K, const double* Ns, int flags) {
   QT_ENTER(h);
   if (!A || !Ns || S < 1 || K < 1) return fail(QT_ERR_ARG, "bad set_povm arguments");
-  if (int r = alloc_povm(h, S, K)) return r;
+  if (int r = begin_povm(h, S, K)) return r;
   const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(h->A.ensure((size_t)S * K * h->D * sizeof(double)));
   HIPCHK(hipMemcpyAsync(h->A.p, A, (size_t)S * K * h->D * sizeof(double), kind, h->stream));
   HIPCHK(hipMemcpyAsync(h->Ns.p, Ns, S * sizeof(double), kind, h->stream));
-  return finish_set_povm(h, S, K, true);
+  h->a_loaded = true;
+  {
+    std::vector<double> ns((size_t)S);
+    if (flags & QT_DEVICE_PTR) HIPCHK(hipMemcpy(ns.data(), Ns, ns.size() * sizeof(double), hipMemcpyDeviceToHost));
+    else memcpy(ns.data(), Ns, ns.size() * sizeof(double));
+    h->ns_tot = 0.0;
+    for (double v : ns) h->ns_tot += v;
+  }
+  if (int r = compute_dense_pinv(h)) return r;  // a plain tensor: the dense operands ARE the POVM
+  h->povm_set = true;
+  return 0;
 }
 
 int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, const double* Ns, int flags) {
   QT_ENTER(h);
   if (!povm1 || !Ns || S1 < 1 || K1 < 1) return fail(QT_ERR_ARG, "bad set_povm_product arguments");
-  const int n = h->nq, D = h->D, R1 = S1 * K1;
+  const int n = h->nq, R1 = S1 * K1;
   long long S = 1, K = 1, M = 1;
   for (int q = 0; q < n; ++q) {
     S *= S1;
@@ -478,7 +545,8 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
     M *= R1;
   }
   if (M > (1 << 15)) return fail(QT_ERR_UNSUPPORTED, "product POVM with %lld rows is too large", M);
-  if (int r = alloc_povm(h, (int)S, (int)K)) return r;
+  if (R1 > 255) return fail(QT_ERR_UNSUPPORTED, "one-qubit table with %d rows (> 255)", R1);
+  if (int r = begin_povm(h, (int)S, (int)K)) return r;
   // host copies of the small inputs (table and shots) for the index tables
   std::vector<double> t1((size_t)R1 * 4), ns((size_t)S);
   if (flags & QT_DEVICE_PTR) {
@@ -491,13 +559,20 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
   HIPCHK(h->pr_T.ensure(t1.size() * sizeof(double)));
   HIPCHK(hipMemcpyAsync(h->pr_T.p, t1.data(), t1.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->Ns.p, ns.data(), ns.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  // full tensor (Born kernel, dense fallbacks, process tomography) -- a2, same kernel as qt_povm_kron
-  hipLaunchKernelGGL(qt::k_povm_kron, dim3(grid_for((size_t)M * D)), dim3(256), 0, h->stream, n, h->pr_T.as<double>(), S1,
-                     K1, h->A.as<double>());
-  bool uniform_shots = true;
-  for (long long s_ = 1; s_ < S; ++s_)
-    if (ns[s_] != ns[0]) uniform_shots = false;
-  if (int r = finish_set_povm(h, (int)S, (int)K, !uniform_shots)) return r;
+  double tot = 0.0;
+  bool uniform = true;
+  for (long long s = 0; s < S; ++s) {
+    tot += ns[s];
+    if (ns[s] != ns[0]) uniform = false;
+  }
+  h->ns_tot = tot;
+  if (int r = ensure_kron_digits(h, S1, K1)) return r;
+  // The dense operands (a2 tensor + transposes; Born GEMM, dense fallbacks, process set-up) are cheap at n <= 3 and
+  // built now; at n = 4, 5 (6 x 64 MB at n = 5) the factorised estimators never read them: on demand only.
+  // The dense left inverse is needed by 'lin' when the shots differ between settings (n <= 3).
+  if (n <= 3) {
+    if (int r = uniform ? ensure_dense(h) : compute_dense_pinv(h)) return r;
+  }
   // pinv of the one-qubit table, on the device: inv(T^T T) T^T  ([4][R1]) and its transpose
   HIPCHK(h->pr_P1.ensure((size_t)4 * R1 * sizeof(double)));
   HIPCHK(h->pr_P1T.ensure((size_t)4 * R1 * sizeof(double)));
@@ -508,15 +583,9 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
     hipLaunchKernelGGL(qt::k_gauss_jordan<0>, dim3(1), dim3(1024), 0, h->stream, 4, g, h->info.as<int>());
     hipLaunchKernelGGL(qt::k_gemm<0>, dim3((R1 + 15) / 16, 1), dim3(64), 0, h->stream, 4, R1, 4, g + 4, 8, 0, T, 4, 1, P1,
                        R1);
-    hipLaunchKernelGGL(qt::k_transpose, dim3(1), dim3(256), 0, h->stream, P1, 4, R1, h->pr_P1T.as<double>());
+    launch_transpose<1>(h, P1, 4, R1, h->pr_P1T.as<double>());
   }
   // host-side index bookkeeping: R-order row map, shot weights, stage tables
-  double tot = 0.0;
-  bool uniform = true;
-  for (long long s = 0; s < S; ++s) {
-    tot += ns[s];
-    if (ns[s] != ns[0]) uniform = false;
-  }
   std::vector<int> rmap((size_t)M), fwd, bwd;
   std::vector<double> wrow((size_t)M);
   for (long long mr = 0; mr < M; ++mr) {  // mr = [r_1 .. r_n], r_q = s_q K1 + o_q
@@ -574,6 +643,7 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
   h->prod.uniform = uniform ? 1 : 0;
   h->prod.wuni = ns[0] / tot;
   h->prod.enabled = 1;
+  h->povm_set = true;
   return 0;
 }
 
@@ -603,6 +673,7 @@ int qt_born_probs(qt_handle_t* h, const double* bloch, int B, double* p, int fla
     if (int r = fetch_out(h, dout, p, (size_t)B * h->M, flags)) return r;
     return finish(h, flags);
   }
+  if (int r = ensure_dense(h)) return r;
   const int gx = (h->M + 255) / 256;
   int Mp = (h->M + 15) & ~15;
   if ((Mp & 31) != 16) Mp += 16;  // LDS pitch: 16 mod 32 doubles (see k_born_mfma)
@@ -711,7 +782,7 @@ int qt_chol_param(qt_handle_t* h, const double* rho, int B, double* x, int32_t* 
   if (int r = stage_in(h, h->in0, rho, nel * 2, flags, &din)) return r;
   if (int r = stage_out(h, h->out0, x, nel, flags, &dx)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
-  qt::PovmView pv{nullptr, nullptr, nullptr, 0, qt::ProductView{}};
+  qt::PovmView pv{};
   if (h->nq >= 4) {
     QT_LAUNCH_LARGE(qt::k_chol_param_large, B, 0, 1, (pv, din, B, dx, dst));
   } else {
@@ -732,7 +803,7 @@ int qt_chol_unparam(qt_handle_t* h, const double* x, int B, double* LLh, int fla
   const size_t nel = (size_t)B * h->D;
   if (int r = stage_in(h, h->in0, x, nel, flags, &din)) return r;
   if (int r = stage_out(h, h->out0, LLh, nel * 2, flags, &dout)) return r;
-  qt::PovmView pv{nullptr, nullptr, nullptr, 0, qt::ProductView{}};
+  qt::PovmView pv{};
   if (h->nq >= 4) {
     QT_LAUNCH_LARGE(qt::k_chol_unparam_large, B, 0, 1, (pv, din, B, dout));
   } else {
@@ -947,6 +1018,7 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
   if (!in_states) return fail(QT_ERR_ARG, "null in_states");
   if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "process tomography supports n_qubits 1..2 in this release");
   h->proc_set = false;
+  if (int r = ensure_dense(h)) return r;
   const int d = h->d, D = h->D, M = h->M;
   const size_t C2 = (size_t)D * D, R = (size_t)D * M;
   qt::ProcessState& ps = h->proc;
@@ -972,7 +1044,7 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
   launch_gauss_jordan<1>(h, c2, aug, h->info.as<int>());
   hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(64), 0, h->stream, c2, rr, c2, aug + (size_t)c2 * 2, 2 * c2, 0, lifp, c2, 1,
                      pinv, rr);
-  hipLaunchKernelGGL(qt::k_transpose_c, dim3(grid_for(R * C2)), dim3(256), 0, h->stream, pinv, c2, rr, pinvT);
+  launch_transpose<2>(h, pinv, c2, rr, pinvT);
   int info = 0;
   HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipGetLastError());

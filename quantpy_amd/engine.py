@@ -17,7 +17,18 @@ _STATUS_TEXT = {
     _capi.TRIAL_LINESEARCH: "line search failed (precision loss)",
     _capi.TRIAL_MAXITER: "maximum number of iterations reached",
     _capi.TRIAL_NAN: "NaN encountered",
+    _capi.TRIAL_SHOTS: "per-setting totals of the counts differ from the shots registered with set_povm",
 }
+
+
+def _check_shots(status):
+    """The reference derives the weights N_s / sum N from each trial's own results (state.py:138-141, 194-197); the
+    engine registers them once per POVM, so counts measured with other shot numbers must not pass silently."""
+    bad = np.flatnonzero(np.asarray(status) == _capi.TRIAL_SHOTS)
+    if bad.size:
+        raise ValueError(f"counts of trial(s) {bad[:8].tolist()}{'...' if bad.size > 8 else ''}: per-setting totals are not "
+                         "proportional to the n_measurements registered with set_povm (reconstruct them with their own "
+                         "tomograph / set_povm call)")
 
 
 class EngineError(RuntimeError):
@@ -344,6 +355,7 @@ class Engine:
         status = np.zeros(b, dtype=np.int32)
         self._chk(self.lib.qt_lin_batch(self._h, _ptr(c), b, int(bool(physical)), _ptr(rho), _ptr(bloch), _ptr(status),
                                         _capi.QT_HOST_PTR))
+        _check_shots(status)
         if single:
             return (rho[0], bloch[0]) if return_bloch else rho[0]
         return (rho, bloch) if return_bloch else rho
@@ -399,6 +411,7 @@ class Engine:
         self._chk(self.lib.qt_mle_batch(self._h, _ptr(c), b, _capi.QT_INIT_LIN if init == "lin" else _capi.QT_INIT_MIXED,
                                         int(max_iter), float(tol), _ptr(rho), _ptr(nit), _ptr(nfev), _ptr(fun),
                                         _ptr(status), _capi.QT_HOST_PTR))
+        _check_shots(status)
         if single:
             rho, nit, nfev, fun, status = rho[0], nit[0], nfev[0], fun[0], status[0]
         if return_info:

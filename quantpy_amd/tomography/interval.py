@@ -12,8 +12,11 @@ law.  Its one heavy step, the left inverse of the (state or process) design matr
 (qt_left_inverse); the moment sums are O(M^2) host arithmetic, written in matrix form instead of the
 reference's six-operand einsums.
 
-The convex-programming / MCMC intervals of the reference (MomentFidelity*, Sugiyama, Polytope*,
-Holder, MHMC*) need cvxopt or serial chains and are not provided.
+`MHMCStateInterval` / `MHMCProcessInterval` run their chains on the GPU (qt_mhmc_state / qt_mhmc_process);
+`SugiyamaInterval` and `HolderInterval` are closed-form / compositions over those.  The four intervals that
+need cvxopt's SOCP / LP solvers (MomentFidelity{State,Process}Interval, Polytope{State,Process}Interval) are
+names that raise NotImplementedError: SURVEY.md section 2 row 11 puts them out of scope and the image has no
+cvxopt to validate against.
 """
 from abc import ABC, abstractmethod
 from enum import Enum, auto
@@ -392,8 +395,6 @@ class BootstrapProcessInterval(ConfidenceInterval):
         if self.mode == Mode.STATE:
             raise NotImplementedError("This interval works only for process tomography")
         tmg = self.tmg
-        if self.method != "lifp":
-            raise NotImplementedError("only method='lifp' is on the GPU hot path")
         if self.channel is None:
             if hasattr(tmg, "reconstructed_channel"):
                 self.channel = tmg.reconstructed_channel
@@ -411,7 +412,10 @@ class BootstrapProcessInterval(ConfidenceInterval):
         centre = self.channel.choi
 
         def reconstruct(shard):
-            choi = boot.point_estimate_batch(shard, cptp=self.cptp)
+            # the reference's loop (interval.py:675-680) passes method, states_physical, states_init and cptp;
+            # `tol` and `states_est_method` stay at point_estimate's defaults there, and so they do here
+            choi = boot.point_estimate_batch(shard, method=self.method, cptp=self.cptp,
+                                             states_physical=self.states_physical, states_init=self.states_init)
             if tmg.dst is hs_dst:
                 return get_engine(centre.n_qubits).hs_dist(choi, centre.matrix)
             from ..qobj import Qobj

@@ -137,9 +137,43 @@ class ProcessTomograph:
             self.reconstructed_channel = self.cptp_projection(self.reconstructed_channel)
         return self.reconstructed_channel
 
-    def point_estimate_batch(self, counts, cptp=True):
-        """Extension: counts (B, D, S, K) -> Choi matrices (B, D, D) in one launch."""
-        return self._engine().lifp(np.asarray(counts), cptp=cptp)
+    def point_estimate_batch(self, counts, method="lifp", cptp=True, n_iter=1000, tol=1e-10, states_est_method="lin",
+                             states_physical=True, states_init="lin", pgdb_stop="reference"):
+        """Extension: counts (B, D, S, K) measured with this tomograph's POVM, shots and input states -> Choi
+        matrices (B, D, D), every resample in the same launch(es).  Same estimators and defaults as
+        `point_estimate`; this is what BootstrapProcessInterval runs."""
+        counts = np.asarray(counts)
+        if method == "lifp":
+            return self._engine().lifp(counts, cptp=cptp)
+        if method == "pgdb":
+            return self._engine().pgdb(counts, n_iter=n_iter, tol=tol, stop=pgdb_stop)
+        if method != "states":
+            raise ValueError("Incorrect value for argument `method`")
+        first = self.tomographs[0]
+        eng = get_engine(self.channel.n_qubits)
+        eng.set_povm(first.povm_matrix, first.n_measurements)
+        b, dd = counts.shape[:2]
+        flat = counts.reshape((b * dd,) + counts.shape[2:])
+        if states_est_method == "lin":  # all B * 4^n output states in one launch
+            outs = eng.lin(flat, physical=states_physical)
+        elif states_est_method == "mle":
+            outs, info = eng.mle(flat, init=states_init, max_iter=n_iter, tol=tol, return_info=True)
+            if np.any(info["status"] == 1):
+                raise np.linalg.LinAlgError("starting point of the MLE is not positive definite")
+        else:
+            raise ValueError("Invalid value for argument `method`")
+        outs = outs.reshape((b, dd) + outs.shape[1:])
+        ins = np.stack([np.asarray(s.matrix, dtype=np.complex128) for s in self.input_basis.elements])
+        coeff = self._decomposed_single_entries
+        units = np.einsum("es,sab->eab", coeff, ins)
+        images = np.einsum("es,bsac->beac", coeff, outs)
+        dim = ins.shape[1]
+        choi = np.einsum("eij,bekl->bikjl", units, images).reshape(b, dim * dim, dim * dim)  # sum_e unit_e (x) image_e
+        if cptp:
+            bad = [i for i in range(b) if not Channel(choi[i]).is_cptp(verbose=False)]
+            if bad:
+                choi[bad] = eng.cptp_project(choi[bad], mode="cptp")
+        return choi
 
     @property
     def _lifp_oper(self):

@@ -728,9 +728,106 @@ def gen_holder():
     save("holder", **out)
 
 
+# --------------------------------------------------------------------------------------
+# round 2: what round 1 left unpinned -- if_dst / trace_dst (a17), warm_start accumulation
+# (state.py:116-124, process.py:122-129), BootstrapProcessInterval from the reference itself
+# (interval.py:615-685) incl. n = 2 and the 'states' / 'pgdb' methods
+# --------------------------------------------------------------------------------------
+def gen_leftovers():
+    import time
+
+    out = {}
+    # ---- a17: geometry.py:5-56 on full-rank, rank-deficient, pure and identical pairs -----------------
+    pairs = []
+    for n in (1, 2, 3):
+        d = 2**n
+        rng = np.random.default_rng(900 + n)
+        full_a, full_b = ginibre_state(rng, d), ginibre_state(rng, d)
+        low_a, low_b = ginibre_state(rng, d, rank=max(1, d // 2)), ginibre_state(rng, d, rank=max(1, d // 2))
+        pure_a, pure_b = ginibre_state(rng, d, rank=1), ginibre_state(rng, d, rank=1)
+        near = full_a + 1e-6 * (full_b - full_a)
+        pairs += [(full_a, full_b), (full_a, low_a), (low_a, low_b), (pure_a, full_a), (pure_a, pure_b),
+                  (pure_a, pure_a), (full_a, near), (np.eye(d) / d, pure_b)]
+    out["geo_n_pairs"] = np.array(len(pairs))
+    for i, (a, b) in enumerate(pairs):
+        out[f"geo{i}_a"], out[f"geo{i}_b"] = a, b
+        out[f"geo{i}_hs"] = np.array(float(qp.hs_dst(a, b)))
+        out[f"geo{i}_trace"] = np.array(float(qp.trace_dst(qp.Qobj(a), qp.Qobj(b))))
+        out[f"geo{i}_if"] = np.array(float(qp.if_dst(a, b)))
+    print("   geometry:", len(pairs), "pairs; if_dst of a pure state with itself =", float(out["geo5_if"]))
+
+    # ---- warm_start, state tomography ------------------------------------------------------------------
+    for tag, n, first, second in (("W1", 1, 1000, 400), ("W2", 2, 1000, np.arange(1, 10) * 100), ("W3", 3, 5000, 5000)):
+        state = qp.Qobj(ginibre_state(np.random.default_rng(70 + n), 2**n))
+        np.random.seed(100 + n)
+        t = qp.StateTomograph(state)
+        t.experiment(first, "proj-set")
+        t.experiment(second, "proj-set", warm_start=True)
+        out[tag + "_state"] = state.matrix
+        out[tag + "_second"] = np.asarray(second)
+        out[tag + "_povm"] = t.povm_matrix
+        out[tag + "_results"] = t.results
+        out[tag + "_nmeas"] = t.n_measurements
+        out[tag + "_lin_unphys"] = t.point_estimate("lin", physical=False).matrix
+        out[tag + "_lin"] = t.point_estimate("lin").matrix
+        out[tag + "_mle"] = t.point_estimate("mle").matrix
+        out[tag + "_mle_nit"] = np.array(_CAPTURE["res"].nit)
+        # a third round on top (still warm)
+        t.experiment(first, "proj-set", warm_start=True)
+        out[tag + "_results3"] = t.results
+        out[tag + "_povm3"] = t.povm_matrix
+        out[tag + "_lin3"] = t.point_estimate("lin").matrix
+    # ---- warm_start, process tomography ---------------------------------------------------------------
+    for tag, n, ch in (("WP1", 1, qp.channel.depolarizing(0.15, 1)), ("WP2", 2, qp.channel.depolarizing(0.1, 2))):
+        np.random.seed(200 + n)
+        pt = qp.ProcessTomograph(ch)
+        pt.experiment(2000, "proj-set")
+        pt.experiment(1000, "proj-set", warm_start=True)
+        out[tag + "_results"] = pt.results
+        out[tag + "_povm"] = pt.tomographs[0].povm_matrix
+        out[tag + "_nmeas"] = pt.tomographs[0].n_measurements
+        out[tag + "_choi_raw"] = pt.point_estimate("lifp", cptp=False).choi.matrix
+        out[tag + "_choi"] = pt.point_estimate("lifp", cptp=True).choi.matrix
+        print(f"   {tag}: warm-started process, results {pt.results.shape}")
+
+    # ---- BootstrapProcessInterval from the reference itself -------------------------------------------
+    cls = np.array([0.5, 0.9, 0.95])
+    for tag, n, method, n_points, shots in (("BP2lifp", 2, "lifp", 6, 3000), ("BP1lifp", 1, "lifp", 40, 1000),
+                                             ("BP1states", 1, "states", 24, 1000), ("BP1pgdb", 1, "pgdb", 3, 1000)):
+        t0 = time.time()
+        np.random.seed(300 + n)
+        pt = qp.ProcessTomograph(qp.channel.depolarizing(0.1, n))
+        pt.experiment(shots, "proj-set")
+        centre = pt.point_estimate(method)
+        out[tag + "_counts0"] = pt.results
+        out[tag + "_centre"] = centre.choi.matrix
+        # replay of interval.py:673-682 recording every resample
+        np.random.seed(5150)
+        boot = qp.ProcessTomograph(centre, pt.input_states, pt.dst)
+        cs, ds, ch_ = [], [], []
+        for _ in range(n_points):
+            boot.experiment(pt.tomographs[0].n_measurements, povm=pt.tomographs[0].povm_matrix)
+            est = boot.point_estimate(method=method, states_physical=True, states_init="lin", cptp=True)
+            cs.append(boot.results.copy())
+            ch_.append(est.choi.matrix)
+            ds.append(pt.dst(est.choi, centre.choi))
+        np.random.seed(5150)
+        iv = qp.BootstrapProcessInterval(pt, n_points=n_points, method=method)
+        dist, cl = iv(cls)
+        assert np.array_equal(np.sort(ds), iv.cl_to_dist.y), "replay differs from the reference class"
+        out[tag + "_boot_counts"] = np.stack(cs)
+        out[tag + "_boot_choi"] = np.stack(ch_)
+        out[tag + "_boot_dist"] = np.array(ds)
+        out[tag + "_cl_dist"] = np.array(dist)
+        out[tag + "_nmeas"] = pt.tomographs[0].n_measurements
+        print(f"   {tag}: quantiles {dist}  ({time.time() - t0:.1f} s)")
+    out["conf_levels"] = cls
+    save("leftovers", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large",
-                             "pgdb", "constr", "mhmc", "holder"]
+                             "pgdb", "constr", "mhmc", "holder", "leftovers"]
     table = {
         "operators": gen_operators,
         "states": gen_states_and_born,
@@ -745,6 +842,7 @@ if __name__ == "__main__":
         "constr": gen_constr,
         "mhmc": gen_mhmc,
         "holder": gen_holder,
+        "leftovers": gen_leftovers,
     }
     for w in which:
         print(f"[{w}]")

@@ -104,3 +104,84 @@ def test_device_sort_and_quantiles_match_numpy_and_interp1d(n):
     assert np.array_equal(xd.cpu().numpy(), srt) and np.array_equal(qd, q)
     with pytest.raises(ValueError):
         eng.sort_quantiles(x, [1.5])
+
+
+def test_mismatched_shots_are_flagged_not_silently_reweighted(oracle):
+    """the reference takes N_s / sum N from each trial's own results (state.py:138-141,
+    194-197); counts whose per-setting totals are not proportional to the registered shots must raise / carry
+    QT_TRIAL_SHOTS, proportional ones (all settings scaled alike) must pass with the same answer."""
+    import torch
+
+    import quantpy_amd as qp
+    from quantpy_amd import _capi
+
+    for n in (2, 4):
+        d = 2**n
+        a = qp.generate_measurement_matrix("proj-set", n)
+        ad = np.asarray(a)
+        rng = np.random.default_rng(n)
+        g = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        rho = g @ g.conj().T
+        rho /= np.trace(rho)
+        np.random.seed(5)
+        bloch = oracle.bloch_from_matrix(rho)
+        good = np.stack([oracle.sample_counts(ad, bloch, 1000) for _ in range(5)])
+        eng = qp.get_engine(n)
+        eng.set_povm(a, good[0].sum(-1))
+        want_lin, want_mle = eng.lin(good), eng.mle(good)
+        bad = good.copy()
+        bad[3, 2, 0] += 1  # one stray count in one setting of one trial
+        for call in (eng.lin, eng.mle):
+            with pytest.raises(ValueError, match="per-setting totals"):
+                call(bad)
+        st = torch.zeros(5, dtype=torch.int32, device="cuda")
+        out = torch.empty((5, d, d), dtype=torch.complex128, device="cuda")
+        eng.mle_dev(torch.from_numpy(bad).cuda(), out, status=st)
+        eng.sync()
+        assert st.cpu().tolist() == [0, 0, 0, _capi.TRIAL_SHOTS, 0]
+        assert np.array_equal(out.cpu().numpy()[[0, 1, 2, 4]], want_mle[[0, 1, 2, 4]])  # the other trials are untouched
+        doubled = np.stack([oracle.sample_counts(ad, bloch, 2000) for _ in range(2)])  # proportional: same weights
+        assert np.abs(eng.lin(doubled)[0] - oracle.lin_estimate(doubled[0], ad)).max() < 1e-10
+        assert np.array_equal(eng.lin(good), want_lin)
+    t = qp.StateTomograph(qp.Qobj(rho))
+    np.random.seed(6)
+    t.experiment(1000, "proj-set")
+    with pytest.raises(ValueError, match="per-setting totals"):
+        t.point_estimate_batch(bad)
+
+
+def test_product_povm_at_n5_registers_without_dense_operands(oracle):
+    """qt_set_povm_product(n = 5) used to allocate 6 x 63.7 MB and assemble A, A^T, A', A'^T that
+    the factorised estimators never read.  Now < 100 MB, and the dense operands / left inverse appear on demand."""
+    import torch
+
+    import quantpy_amd as qp
+    from quantpy_amd.engine import Engine
+
+    torch.cuda.synchronize()
+    eng = Engine(5)
+    a = qp.generate_measurement_matrix("proj-set", 5)
+    free0, _ = torch.cuda.mem_get_info()
+    eng.set_povm(a, np.full(243, 1000.0))
+    assert eng.product
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 100e6, (free0 - free1) / 1e6
+    rng = np.random.default_rng(3)
+    g = rng.standard_normal((32, 32)) + 1j * rng.standard_normal((32, 32))
+    rho = g @ g.conj().T
+    rho /= np.trace(rho)
+    bl = oracle.bloch_from_matrix(rho)
+    p = eng.born_probs(bl)  # factorised Born kernel, no dense operand
+    assert np.abs(p - np.clip(np.einsum("skd,d->sk", np.asarray(a), bl) * 32, 0, 1)).max() < 1e-14
+    free2, _ = torch.cuda.mem_get_info()
+    assert free0 - free2 < 120e6
+    eng.close()
+    e4 = Engine(4)
+    a4 = qp.generate_measurement_matrix("proj-set", 4)
+    ns = np.full(81, 500.0)
+    e4.set_povm(a4, ns)
+    inv = e4.left_inverse()  # on demand: dense tensor, transposes, Gram GEMM, Gauss-Jordan
+    aw = oracle.weighted_povm(np.asarray(a4), ns)
+    assert np.abs(inv @ aw - np.eye(256)).max() < 1e-9
+    assert np.abs(inv - oracle.left_inv(aw)).max() < 1e-8
+    e4.close()

@@ -287,3 +287,72 @@ def test_mhmc_process_interval_against_reference(oracle):
         assert np.abs(np.stack(samples) - g[key + "_samples"]).max() < 1e-10, key
         assert np.abs(dist - g[key + "_dist"]).max() < 1e-10, key
         assert abs(rate - float(g[key + "_rate"])) < 1e-12, key
+
+
+# ---- round 2: leftovers.npz (if_dst / trace_dst, warm_start, BootstrapProcessInterval) -----------------------
+def test_geometry_distances_against_reference(oracle):
+    """a17: geometry.py:5-56 on 24 pairs (full rank, rank deficient, pure, identical, nearly equal).  The
+    restatement uses scipy.linalg.sqrtm exactly as the reference does, so it must agree to rounding; the eigh /
+    SVD based `infidelity` the parity harness uses agrees to sqrtm's accuracy on singular arguments (~1e-8)."""
+    g = load_golden("leftovers")
+    worst_eigh = 0.0
+    for i in range(int(g["geo_n_pairs"])):
+        a, b = g[f"geo{i}_a"], g[f"geo{i}_b"]
+        assert abs(oracle.hs_dst(a, b) - float(g[f"geo{i}_hs"])) < 1e-15
+        assert abs(oracle.trace_dst(a, b) - float(g[f"geo{i}_trace"])) < 1e-13
+        assert abs(oracle.if_dst(a, b) - float(g[f"geo{i}_if"])) < 1e-13
+        worst_eigh = max(worst_eigh, abs(oracle.infidelity(a, b) - float(g[f"geo{i}_if"])))
+    assert worst_eigh < 2e-7, worst_eigh
+
+
+def test_warm_start_accumulation_against_reference(oracle):
+    """state.py:116-124 / process.py:122-129: counts bit-exact through the RNG call order, the stacked POVM, and
+    the estimators on the accumulated data."""
+    g = load_golden("leftovers")
+    for tag, n, first, seed in (("W1", 1, 1000, 101), ("W2", 2, 1000, 102), ("W3", 3, 5000, 103)):
+        a = oracle.measurement_matrix("proj-set", n)
+        bloch = oracle.bloch_from_matrix(g[tag + "_state"])
+        np.random.seed(seed)
+        c1 = oracle.sample_counts(a, bloch, first)
+        second = g[tag + "_second"]
+        c2 = oracle.sample_counts(a, bloch, int(second) if second.ndim == 0 else second)
+        povm, res = oracle.warm_start_stack(a, c1, a, c2)
+        assert np.array_equal(res, g[tag + "_results"]) and np.array_equal(povm, g[tag + "_povm"])
+        assert np.array_equal(res.sum(-1), g[tag + "_nmeas"])
+        assert np.abs(oracle.lin_estimate(res, povm, physical=False) - g[tag + "_lin_unphys"]).max() < 1e-11
+        assert np.abs(oracle.lin_estimate(res, povm) - g[tag + "_lin"]).max() < 1e-11
+        rho, info = oracle.mle_estimate(res, povm, return_info=True)
+        assert info["nit"] == int(g[tag + "_mle_nit"]) and abs(oracle.infidelity(rho, g[tag + "_mle"])) < 1e-9
+        c3 = oracle.sample_counts(a, bloch, first)
+        povm3, res3 = oracle.warm_start_stack(povm, res, a, c3)
+        assert np.array_equal(res3, g[tag + "_results3"]) and np.array_equal(povm3, g[tag + "_povm3"])
+        assert np.abs(oracle.lin_estimate(res3, povm3) - g[tag + "_lin3"]).max() < 1e-11
+    for tag, n in (("WP1", 1), ("WP2", 2)):
+        counts, povm = g[tag + "_results"], g[tag + "_povm"]
+        ins = oracle.input_states("proj4", n)
+        raw = oracle.lifp_estimate(counts, povm, ins)
+        assert np.abs(raw - g[tag + "_choi_raw"]).max() < 1e-10
+        assert np.abs(oracle.cptp_projection(raw, n) - g[tag + "_choi"]).max() < 1e-10
+
+
+def test_bootstrap_process_interval_against_reference(oracle):
+    """interval.py:615-685 run by the reference itself (n = 2 'lifp'; n = 1 'lifp', 'states', 'pgdb'): the oracle's
+    estimators on the recorded resamples reproduce every bootstrap Choi matrix and distance."""
+    g = load_golden("leftovers")
+    for tag, n, method in (("BP2lifp", 2, "lifp"), ("BP1lifp", 1, "lifp"), ("BP1states", 1, "states"), ("BP1pgdb", 1, "pgdb")):
+        povm = oracle.measurement_matrix("proj-set", n)
+        ins = oracle.input_states("proj4", n)
+        centre = g[tag + "_centre"]
+        dists = []
+        for counts, want in zip(g[tag + "_boot_counts"][: (2 if method == "pgdb" else None)], g[tag + "_boot_choi"]):
+            if method == "lifp":
+                est = oracle.cptp_projection(oracle.lifp_estimate(counts, povm, ins), n)
+            elif method == "states":
+                est = oracle.states_estimate(counts, povm, ins, n)
+            else:
+                est = oracle.pgdb_estimate(counts, povm, ins, n_iter=20)  # the estimate never moves (DESIGN.md 6)
+            assert np.abs(est - want).max() < 1e-9, tag
+            dists.append(oracle.hs_dst(est, centre))
+        if method != "pgdb":
+            assert np.abs(np.array(dists) - g[tag + "_boot_dist"]).max() < 1e-9
+            assert np.abs(oracle.quantiles(np.sort(dists), g["conf_levels"]) - g[tag + "_cl_dist"]).max() < 1e-9

@@ -546,20 +546,30 @@ struct Small {
   // of that set-up; up to 4 values per lane are held in registers until load_freq picks them up.
   struct Prefetch {
     int64_t v[4];
-    double ns;  // N_s of setting s = lane (the shots check of load_freq)
-    bool ok;
+    double ns[4];  // N_s of the settings rows l + q G belong to (segmented check) or of setting s = lane (ns[0])
+    bool ok, seg;  // seg: K in {2, 4, 8, 16} divides G -- the K outcomes of a setting sit in K neighbouring lanes
   };
   __device__ __forceinline__ static void prefetch_counts(Prefetch& pf, const int64_t* counts, const PovmView& pv) {
-    const int l = (threadIdx.x & 63) % G, M = pv.M;
+    const int l = (threadIdx.x & 63) % G, M = pv.M, K = pv.K;
     pf.ok = M <= 4 * G;
+    pf.seg = pf.ok && pv.Ns && (K == 2 || K == 4 || K == 8 || K == 16) && G % K == 0;
     if (pf.ok) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int m = l + q * G;
         pf.v[q] = counts[m < M ? m : M - 1];
+        if (pf.seg) pf.ns[q] = pv.Ns[(m < M ? m : M - 1) / K];
       }
     }
-    pf.ns = pv.Ns ? pv.Ns[l < pv.S ? l : pv.S - 1] : 0.0;
+    if (!pf.seg) pf.ns[0] = pv.Ns ? pv.Ns[l < pv.S ? l : pv.S - 1] : 0.0;
+  }
+  // sum over the aligned group of KK neighbouring lanes this lane belongs to (KK = 2, 4, 8, 16)
+  __device__ __forceinline__ static double segsum(double v, int KK) {
+    v += dpp_f64<0xB1>(v);
+    if (KK >= 4) v += dpp_f64<0x4E>(v);
+    if (KK >= 8) v += dpp_f64<0x141>(v);
+    if (KK >= 16) v += dpp_f64<0x140>(v);
+    return v;
   }
   // Returns false when the trial's per-setting totals are not proportional to the registered shots.
   __device__ static bool load_freq(const Ctx& c, const int64_t* counts, const Prefetch* pf = nullptr) {
@@ -597,20 +607,30 @@ struct Small {
     } else {
       for (int m = c.l; m < c.M; m += G) c.freq()[m] = raw[m] * inv;
     }
-    // shots check: lane s sums the K outcomes of setting s (raw is in the caller's (S, K) order)
-    double bad = 0.0;
-    if (c.pv.Ns) {
+    // shots check (state.py:138-141, 194-197): per-setting totals against the registered N_s
+    bool bad = false;
+    if (pf && pf->seg) {  // the K outcomes of a setting are K neighbouring lanes of one prefetched value: DPP adds
+      const int K = c.pv.K;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = c.l + q * G;
+        const double t = segsum(m < c.M ? (double)pf->v[q] : 0.0, K);
+        bad |= m < c.M && !shots_match(t, total, pf->ns[q], c.pv.ns_tot);
+      }
+    } else if (c.pv.Ns) {  // general shape: lane s sums the K outcomes of setting s (raw is in (S, K) order)
       const int K = c.pv.K;
       for (int s = c.l; s < c.pv.S; s += G) {
         double t = 0.0;
         for (int k = 0; k < K; ++k) t += raw[s * K + k];
-        const double ns = (pf && s == c.l) ? pf->ns : c.pv.Ns[s];
-        if (!shots_match(t, total, ns, c.pv.ns_tot)) bad = 1.0;
+        const double ns = (pf && s == c.l) ? pf->ns[0] : c.pv.Ns[s];
+        bad |= !shots_match(t, total, ns, c.pv.ns_tot);
       }
     }
-    const bool shots_ok = !(gmax<G>(bad) > 0.0);
+    const unsigned long long votes = __builtin_amdgcn_ballot_w64(bad);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mine = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << (lane / G * G));
     wave_sync();
-    return shots_ok;
+    return (votes & mine) == 0ull;
   }
 
   // ---- factorised contractions for product POVMs -----------------------------------------------

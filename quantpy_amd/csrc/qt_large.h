@@ -27,6 +27,7 @@
 
 #include "qt_jacobi_wg.h"
 #include "qt_linesearch.h"
+#include "qt_signclip_wg.h"
 #include "qt_small.h"
 
 namespace qt {
@@ -49,7 +50,8 @@ struct Large {
   static constexpr int oLam = oVec + D;        // [d]
   static constexpr int oRed = oLam + d;        // [32] reduction scratch
   static constexpr int oRot = oRed + 32;       // Jacobi rotations of this round and the next: 2 x (cos [d], w [d] complex)
-  static constexpr int oTab = oRot + 6 * d;    // tabT [R1][4], tabP [R1][4]
+  static constexpr int oLs = oRot + 6 * d;     // line-search state parked across an evaluation (LineSearch::SLOTS)
+  static constexpr int oTab = oLs + LineSearch::SLOTS;  // tabT [R1][4], tabP [R1][4]
   __host__ __device__ static int x_doubles(int M) { return (M > MAT ? M : MAT) + (M & 1); }
   __host__ __device__ static int y_doubles(int M, int R1) {
     int y = (M / R1) * 4;  // R1^(n-1) * 4: the largest stage that lands in Y
@@ -74,6 +76,7 @@ struct Large {
     __device__ __forceinline__ double* vec() const { return sm + oVec; }
     __device__ __forceinline__ double* lam() const { return sm + oLam; }
     __device__ __forceinline__ double* red() const { return sm + oRed; }
+    __device__ __forceinline__ double* lsbuf() const { return sm + oLs; }
     __device__ __forceinline__ double* tabT() const { return sm + oTab; }
     __device__ __forceinline__ double* tabP() const { return sm + oTab + 4 * pr.R1; }
     __device__ __forceinline__ double* X() const { return sm + oTab + 8 * pr.R1; }
@@ -175,6 +178,8 @@ struct Large {
   }
   __device__ static double bloch_of(const Ctx& c, const cd* m) {
     cd s{0.0, 0.0};
+#pragma unroll 8  // fully unrolled, hipcc issues all d 16-byte reads at once: 128 VGPRs at d = 32, the cap of a 1024-thread
+                  // workgroup -- the spills of k_nll_large<5> / k_mle_large<5> sat exactly here (ISA, round 2)
     for (int r = 0; r < d; ++r) {
       const cd e = m[r * LD + (r ^ c.xm)];
       const double sg = (__popc(r & c.zm) & 1) ? -1.0 : 1.0;
@@ -312,13 +317,23 @@ struct Large {
     return r;
   }
 
-  // ---- a7: Jacobi eigenvalue clip: qt_jacobi_wg.h.  The A image alternates between the Y overlay and the L region
-  // (which holds nothing live here: the factorisation that called us has failed), V goes to the X overlay.
+  // ---- a7: eigenvalue clip U max(v, eps) U^dagger / Tr.  Default: through the matrix sign function on the FP64 matrix
+  // cores (qt_signclip_wg.h; three d x d images: the Y overlay, the L region -- which holds nothing live here, the
+  // factorisation that called us has failed -- and the X overlay).  kJacobiClip selects the cyclic Jacobi
+  // eigensolver of qt_jacobi_wg.h instead (the version before round 2; kept for cross-checks).
+  static constexpr bool kJacobiClip = false;
   __device__ static cd psd_project(const Ctx& c, cd a, double eps) {
-    using J = JacobiWG<d, NT, true>;
-    static_assert(J::LDV == LD, "the eigenvector image uses the pitch of the other d x d images");
-    const typename J::Lds o{(int)(c.Y() - c.sm), oL, oRot, (int)(c.X() - c.sm), oLam, oRed};
-    return J::clip(c.t, a, eps, c.sm, o, true);
+    if constexpr (kJacobiClip) {
+      using J = JacobiWG<d, NT, true>;
+      static_assert(J::LDV == LD, "the eigenvector image uses the pitch of the other d x d images");
+      const typename J::Lds o{(int)(c.Y() - c.sm), oL, oRot, (int)(c.X() - c.sm), oLam, oRed};
+      return J::clip(c.t, a, eps, c.sm, o, true);
+    } else {
+      using SC = SignClipWG<d, NT>;
+      static_assert(SC::P == LD, "the images use the pitch of the other d x d images");
+      const typename SC::Lds o{(int)(c.Y() - c.sm), oL, (int)(c.X() - c.sm), oRed};
+      return SC::clip(c.t, a, eps, c.sm, o, true);
+    }
   }
 
   // ---- a8: Cholesky (image in the A overlay, factor in L) ------------------------------------------
@@ -402,6 +417,11 @@ struct Large {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the builtin has no host-side declaration)
     __builtin_assume(__builtin_amdgcn_is_shared(c.sm));
 #endif
+    nll_grad_inl(c, xt, f, gt);
+  }
+  // The same evaluation inlined: for kernels that evaluate ONCE (k_nll_large, k_mle_large_start).  An out-of-line
+  // callee has to save the callee-saved registers it touches (176 bytes of scratch per lane in k_nll_large).
+  __device__ __forceinline__ static void nll_grad_inl(const Ctx& c, double xt, double& f, double& gt) {
     double tr;
     QT_STAMP(11);
     const cd m = build_llh(c, xt, tr);
@@ -561,19 +581,28 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_nll_large(PovmView pv, const 
   typename S::Ctx c;
   S::make_ctx(c, smem, pv, counts + (size_t)b * pv.M);
   double fv, gt;
-  S::nll_grad(c, x[(size_t)b * S::D + c.t], fv, gt);
+  S::nll_grad_inl(c, x[(size_t)b * S::D + c.t], fv, gt);
   if (c.t == 0) f[b] = fv;
   if (grad) grad[(size_t)b * S::D + c.t] = gt;
 }
 
-// a10 for n = 4, 5: the whole MLE of one trial.  `pairs` = B x max_iter x 2 x D doubles of workspace
-// ((s_i, y_i) of every accepted step); LDS carries rho_i and the two-loop alphas (2 x max_iter doubles).
+// a10 for n = 4, 5 in two kernels (as at n <= 3): the whole MLE of one trial used to be ONE kernel whose BFGS loop --
+// line-search state, out-of-line evaluation -- dictated the register allocation of the start phase too (110 VGPRs
+// spilled, 432 bytes of scratch per lane at n = 5, every phase reloading through scratch).
+//   k_mle_large_start: start point (state.py:205-212), Cholesky parametrisation, first (value, gradient); trials whose
+//     gradient already meets gtol -- every full-rank high-shot one, SURVEY 0 fact 2 -- are finished here; the rest hand
+//     x0, g0, f0 to
+//   k_mle_large_bfgs: scipy's BFGS loop for the trials that iterate (workgroups of finished trials leave at once).
+//     `pairs` = nb x max_iter x 2 x D doubles of workspace ((s_i, y_i) of every accepted step); LDS carries rho_i and
+//     the two-loop alphas (2 x max_iter doubles) and, across each out-of-line evaluation, the line-search state.
 template <int NQ>
-__global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const int64_t* __restrict__ counts, int B,
-                                                             int init, int max_iter, double gtol, double* __restrict__ rho,
-                                                             int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
-                                                             double* __restrict__ fun_out, int32_t* __restrict__ status_out,
-                                                             double* __restrict__ pairs) {
+__global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large_start(PovmView pv, const int64_t* __restrict__ counts, int B,
+                                                                   int init, int max_iter, double gtol,
+                                                                   double* __restrict__ rho, int32_t* __restrict__ nit_out,
+                                                                   int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,
+                                                                   int32_t* __restrict__ status_out, double* __restrict__ ws_x,
+                                                                   double* __restrict__ ws_g, double* __restrict__ ws_f,
+                                                                   int32_t* __restrict__ ws_active) {
   using S = Large<NQ>;
   constexpr int D = S::D, d = S::d;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -595,38 +624,86 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
   }
   QT_STAMP(8);
   double fk = 0.0, gk = 0.0;
-  int kiter = 0, nfev = 0, status = !c.shots_ok ? 5 : (ok ? 0 : 1);
-  bool active = ok != 0 && c.shots_ok;
-  if (active) {
-    S::nll_grad(c, xk, fk, gk);
+  int status = !c.shots_ok ? 5 : (ok ? 0 : 1);
+  bool iterate = false;
+  if (status == 0) {  // uniform: one trial per workgroup
+    S::nll_grad_inl(c, xk, fk, gk);
     QT_STAMP(9);
-    nfev = 1;
     const double gnorm = S::bmax(c, fabs(gk));
-    if (!(gnorm > gtol) || !(0 < max_iter)) active = false;
+    iterate = (gnorm > gtol) && (0 < max_iter);
+    if (!iterate) {
+      const double xn = S::bmax(c, fabs(xk));
+      if (0 >= max_iter) status = 3;
+      else if (gnorm != gnorm || fk != fk || xn != xn) status = 4;
+    }
   }
+  // what the trial returns if BFGS does not move: L L^dagger / Tr at x_k (state.py:214-215)
+  double tr;
+  const cd m = S::build_llh(c, xk, tr);
+  double* out = rho + ((size_t)b * D + c.t) * 2;
+  out[0] = m.re / tr;
+  out[1] = m.im / tr;
+  if (iterate) {
+    ws_x[(size_t)b * D + c.t] = xk;
+    ws_g[(size_t)b * D + c.t] = gk;
+  }
+  QT_STAMP(10);
+  if (c.t == 0) {
+    if (iterate) ws_f[b] = fk;
+    ws_active[b] = iterate ? 1 : 0;
+    if (nit_out) nit_out[b] = 0;
+    if (nfev_out) nfev_out[b] = status == 0 || status >= 3 ? (status == 5 ? 0 : 1) : 0;
+    if (fun_out) fun_out[b] = fk;
+    if (status_out) status_out[b] = status;
+  }
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B,
+                                                                  int max_iter, double gtol, double* __restrict__ rho,
+                                                                  int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
+                                                                  double* __restrict__ fun_out, int32_t* __restrict__ status_out,
+                                                                  const double* __restrict__ ws_x, const double* __restrict__ ws_g,
+                                                                  const double* __restrict__ ws_f,
+                                                                  const int32_t* __restrict__ ws_active,
+                                                                  double* __restrict__ pairs) {
+  using S = Large<NQ>;
+  constexpr int D = S::D;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x;
+  if (b >= B || ws_active[b] == 0) return;  // uniform per workgroup
+  typename S::Ctx c;
+  S::make_ctx(c, smem, pv, counts + (size_t)b * pv.M);
+  double xk = ws_x[(size_t)b * D + c.t], gk = ws_g[(size_t)b * D + c.t], fk = ws_f[b];
+  int kiter = 0, nfev = 1, status = 0;
   double* my = pairs + (size_t)b * max_iter * 2 * D + c.t;  // s_i[t] at my[2 i D], y_i[t] at my[(2 i + 1) D]
   double* prho = c.pair_rho();
   double* palpha = prho + max_iter;
-  double old_old = 0.0, pk = 0.0, stp = 0.0;
-  LineSearch ls;
-  if (active) {
-    old_old = fk + sqrt(S::bsum(c, gk * gk)) / 2.0;
-    pk = -gk;  // H_0 = I
+  double* lsb = c.lsbuf();
+  double old_old = fk + sqrt(S::bsum(c, gk * gk)) / 2.0;
+  double pk = -gk, stp = 0.0;  // H_0 = I
+  {
+    LineSearch ls;
     ls.start(fk, old_old, S::bsum(c, gk * pk), &stp);
+    if (c.t == 0) ls.save(lsb);
   }
   const int eval_cap = (max_iter + 2) * 130;
-  while (active) {  // uniform: one trial per workgroup, every thread holds the same scalars
+  while (true) {  // uniform: one trial per workgroup, every thread holds the same scalars
     double ft, gt;
-    S::nll_grad(c, xk + stp * pk, ft, gt);
+    S::nll_grad(c, xk + stp * pk, ft, gt);  // (barriers inside publish the parked line-search state)
     if (++nfev > eval_cap) {
       status = 2;
       break;
     }
     const double dphi = S::bsum(c, gt * pk);
+    LineSearch ls;
+    ls.load(lsb);
     double next = stp;
     const int r = ls.advance(stp, ft, dphi, &next);
     if (r == LS_EVAL) {
       stp = next;
+      __syncthreads();  // every thread has read the old state
+      if (c.t == 0) ls.save(lsb);
       continue;
     }
     if (r == LS_FAIL) {
@@ -673,9 +750,10 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
       q = fma(si, palpha[i] - bb, q);
     }
     pk = -q;
-    ls.start(fk, old_old, S::bsum(c, gk * pk), &stp);
+    ls.start(fk, old_old, S::bsum(c, gk * pk), &stp);  // (the barriers of bsum are behind every read of lsb)
+    if (c.t == 0) ls.save(lsb);
   }
-  if (status == 0 && ok) {  // (status 5 trials never evaluated: fk = 0, the start point is returned)
+  if (status == 0) {
     const double gn = S::bmax(c, fabs(gk));
     const double xn = S::bmax(c, fabs(xk));
     if (kiter >= max_iter) status = 3;
@@ -686,7 +764,6 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large(PovmView pv, const 
   double* out = rho + ((size_t)b * D + c.t) * 2;
   out[0] = m.re / tr;
   out[1] = m.im / tr;
-  QT_STAMP(10);
   if (c.t == 0) {
     if (nit_out) nit_out[b] = kiter;
     if (nfev_out) nfev_out[b] = nfev;

@@ -42,6 +42,25 @@ struct LineSearch {
 
   static constexpr double C1 = 1e-4, C2 = 0.9, AMAX = 1e100, AMIN = 1e-100, XTOL = 1e-14;
 
+  // The whole state as SLOTS doubles (integers stored exactly as doubles): the workgroup-per-trial kernels park it
+  // in LDS across an evaluation -- every thread holds the same values, thread 0 writes, everybody reads back --
+  // instead of keeping ~70 registers per thread alive through the out-of-line NLL call.
+  static constexpr int SLOTS = 32;
+  QT_HD void save(double* p) const {
+    p[0] = phi0; p[1] = old_phi0; p[2] = derphi0; p[3] = mode; p[4] = brackt; p[5] = stage; p[6] = evals;
+    p[7] = gtest; p[8] = width; p[9] = width1; p[10] = stx; p[11] = fx; p[12] = gx; p[13] = sty; p[14] = fy;
+    p[15] = gy; p[16] = stmin; p[17] = stmax; p[18] = alpha0; p[19] = alpha1; p[20] = phi_a0; p[21] = phi_a1;
+    p[22] = derphi_a0; p[23] = it; p[24] = a_lo; p[25] = a_hi; p[26] = phi_lo; p[27] = phi_hi; p[28] = derphi_lo;
+    p[29] = phi_rec; p[30] = a_rec; p[31] = zi;
+  }
+  QT_HD void load(const double* p) {
+    phi0 = p[0]; old_phi0 = p[1]; derphi0 = p[2]; mode = (int)p[3]; brackt = (int)p[4]; stage = (int)p[5];
+    evals = (int)p[6]; gtest = p[7]; width = p[8]; width1 = p[9]; stx = p[10]; fx = p[11]; gx = p[12]; sty = p[13];
+    fy = p[14]; gy = p[15]; stmin = p[16]; stmax = p[17]; alpha0 = p[18]; alpha1 = p[19]; phi_a0 = p[20];
+    phi_a1 = p[21]; derphi_a0 = p[22]; it = (int)p[23]; a_lo = p[24]; a_hi = p[25]; phi_lo = p[26]; phi_hi = p[27];
+    derphi_lo = p[28]; phi_rec = p[29]; a_rec = p[30]; zi = (int)p[31];
+  }
+
   // Python's min(a, b) / max(a, b): the first argument wins ties and NaN comparisons.
   QT_HD static double dmin(double a, double b) { return b < a ? b : a; }
   QT_HD static double dmax(double a, double b) { return b > a ? b : a; }

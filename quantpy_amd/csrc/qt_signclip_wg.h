@@ -1,0 +1,149 @@
+// Workgroup eigenvalue clip  U max(lambda, eps) U^dagger  WITHOUT an eigensolver, for the d x d Hermitian matrices of
+// the n = 4, 5 state kernels (d = 16, 32; one element per thread, thread t = i * d + j) -- a7, state.py:267-273.
+//
+// Why: the clip only needs the projector onto the negative eigenspace,
+//     U max(L, eps) U^dagger = (A + A S) / 2 + eps (I - S) / 2,     S = sign(A) = U sign(L) U^dagger,
+// and sign(A) is the limit of a polynomial matrix iteration that is nothing but d x d complex products -- which run on
+// the FP64 matrix cores (v_mfma_f64_16x16x4_f64), while the cyclic Jacobi of qt_jacobi_wg.h is ~190 rounds of one
+// barrier + one LDS burst each (370 k of the ~620 k clocks of a 5-qubit MLE trial).
+//
+// Iteration on X_0 = A / ||A||_F (spectrum in [-1, 1]); every step is  Y = X^2,  X <- X (alpha I + beta Y):
+//   * lifting, (alpha, beta) = (2, -1): p(x) = 2 x - x^3 has slope 2 at 0, maps [0, 1.089] into itself and keeps
+//     the sign, so an eigenvalue x grows by 2x per step until it sits in ~[0.88, 1.09];
+//   * Newton-Schulz, (3/2, -1/2): quadratic convergence to +-1 once every |1 - x^2| < 1.
+// The switch is decided by res = ||I - Y||_F^2 (a by-product of Y): res < 1/2 bounds every |1 - x_i^2| by 0.71.
+// An eigenvalue that is still unlifted after 40 doublings is below 1e-12 ||A||_F; what it then contributes to the
+// result is wrong by at most its own size, so the cap costs nothing measurable and there is no failure mode that
+// needs a fallback.  Y is re-symmetrised when it is read (one extra LDS read), which keeps rounding from feeding
+// a non-Hermitian component.  Agreement with LAPACK-eigh clipping: ~1e-15 (tests/test_gpu_large.py).
+//
+// Complex product C = A B on the matrix cores: one wavefront per (16 x 16 tile of C, real | imaginary part); the real
+// part accumulates Ar Br - Ai Bi, the imaginary one Ar Bi + Ai Br, over K in steps of 4 (operand layout as k_gemm,
+// qt_ops.h).  Images are complex interleaved with row pitch d + 1 (conflict-free 16-byte operand reads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qt_small.h"
+
+namespace qt {
+
+typedef double sc_v4f64 __attribute__((ext_vector_type(4)));
+
+template <int d, int NT>
+struct SignClipWG {
+  static_assert(NT == d * d && d % 16 == 0 && NT % 64 == 0, "one thread per matrix element, 16 x 16 MFMA tiles");
+  static constexpr int P = d + 1;            // row pitch of the images, in complex elements
+  static constexpr int TPR = d / 16;         // tiles per row
+  static constexpr int NTILE = TPR * TPR;
+  static constexpr int NW = NT / 64;
+  static_assert(2 * NTILE <= NW, "one wavefront per (tile, part)");
+  // three images of d * P complex each (offsets in doubles from the 16-byte aligned LDS base, all even) + red [32]
+  struct Lds {
+    int img0, img1, img2, red;
+  };
+
+  __device__ static double wsum(double* red, double v) {  // identical bits in every thread
+    v = gsum<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];
+    return s;
+  }
+
+  // C = A * B.  Ends with a barrier: C is visible to every thread, A and B may be overwritten.
+  __device__ static void matmul(const cd* A, const cd* B, cd* C) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 2 * NTILE) {  // wave-uniform
+      const int tile = wave >> 1, part = wave & 1;
+      const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
+      const int r16 = lane & 15, kq = lane >> 4;
+      sc_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+      const cd* ap = A + (row0 + r16) * P + kq;
+      const cd* bp = B + kq * P + col0 + r16;
+#pragma unroll
+      for (int k0 = 0; k0 < d; k0 += 4) {
+        const cd a = ap[k0], b = bp[k0 * P];
+        if (part == 0) {
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, acc, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, acc, 0, 0, 0);
+        }
+      }
+      double* cdst = reinterpret_cast<double*>(C) + part;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cdst[((row0 + kq + 4 * r) * P + col0 + r16) * 2] = acc[r];
+    }
+    __syncthreads();
+  }
+
+  // In: this thread's element of a Hermitian matrix.  Out: its element of U max(lambda, eps) U^dagger (/ trace).
+  __device__ static cd clip(const int t, cd a, const double eps, double* sm, const Lds o, const bool normalise) {
+    const int i = t / d, j = t % d, e = i * P + j, et = j * P + i;
+    const double dlt = (i == j) ? 1.0 : 0.0;
+    double* red = sm + o.red;
+    // (images are picked by OFFSET from the LDS base: an array of pointers indexed at run time makes the compiler
+    //  lose the address space and emit flat_* for every access in the loop -- DESIGN.md section 4.5)
+    int xo = o.img0, yo = o.img1;
+    const int wo = o.img2;
+    if (i == j) a.im = 0.0;
+    const double nrm2 = wsum(red, a.re * a.re + a.im * a.im);
+    if (!(nrm2 > 0.0)) {  // the zero matrix (or NaN input): every eigenvalue is clipped to eps
+      const double v = normalise ? dlt / d : dlt * eps;
+      return cd{nrm2 == 0.0 ? v : nrm2, 0.0};
+    }
+    const double scale = 1.0 / sqrt(nrm2);
+    cd x{a.re * scale, a.im * scale};
+    reinterpret_cast<cd*>(sm + xo)[e] = x;
+    __syncthreads();
+    bool lifting = true;
+    int ns_left = 12;
+    for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (wsum returns identical bits)
+      cd* X = reinterpret_cast<cd*>(sm + xo);
+      cd* Y = reinterpret_cast<cd*>(sm + yo);
+      cd* W = reinterpret_cast<cd*>(sm + wo);
+      matmul(X, X, Y);
+      const cd y0 = Y[e], yt = Y[et];
+      const cd y{0.5 * (y0.re + yt.re), 0.5 * (y0.im - yt.im)};  // Hermitian part
+      const double dr = dlt - y.re;
+      const double res = wsum(red, dr * dr + y.im * y.im);
+      if (lifting && (res < 0.5 || k >= 40)) lifting = false;
+      const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);  // one more quadratic step squares the error
+      const double alpha = lifting ? 2.0 : 1.5, beta = lifting ? -1.0 : -0.5;
+      W[e] = cd{fma(beta, y.re, alpha * dlt), beta * y.im};
+      __syncthreads();
+      matmul(X, W, Y);  // X_next lands in Y
+      const int tmp = xo;
+      xo = yo;
+      yo = tmp;
+      if (last || !(res == res)) break;
+    }
+    // S = sign(A) sits in the image at xo.  R = (A + A S) / 2 + eps (I - S) / 2
+    cd* S = reinterpret_cast<cd*>(sm + xo);
+    cd* Y = reinterpret_cast<cd*>(sm + yo);
+    cd* W = reinterpret_cast<cd*>(sm + wo);
+    W[e] = a;
+    __syncthreads();
+    matmul(W, S, Y);
+    const cd as = Y[e], s = S[e];
+    cd r{0.5 * (a.re + as.re) + 0.5 * eps * (dlt - s.re), 0.5 * (a.im + as.im) - 0.5 * eps * s.im};
+    W[e] = r;  // (all reads of W by the product are behind the barrier that ended it)
+    __syncthreads();
+    const cd rt = W[et];
+    r = cd{0.5 * (r.re + rt.re), 0.5 * (r.im - rt.im)};
+    if (i == j) r.im = 0.0;
+    if (!normalise) {
+      __syncthreads();
+      return r;
+    }
+    const double tr = wsum(red, i == j ? r.re : 0.0);  // (barriers inside: W is free again)
+    return cd{r.re / tr, r.im / tr};
+  }
+};
+
+}  // namespace qt

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -92,8 +93,10 @@ struct qt_handle {
   bool proc_set = false;
 
   double ns_tot = 0.0;  // sum of the registered shots per setting
+  bool check_shots = true;  // QTOMO_SKIP_SHOTS_CHECK=1 at qt_create turns the per-trial shots check off
   qt::PovmView view() const {
-    return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod, jtol2, Ns.as<double>(), S, K, ns_tot};
+    return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod, jtol2,
+                        check_shots ? Ns.as<double>() : nullptr, S, K, ns_tot};
   }
   // Jacobi stopping rule off^2 <= jtol2 * ||A||_F^2.  Measured on the C2 batch: the last sweep takes off^2
   // from > 1e-9 to < 1e-28 in one go, so no looser threshold saves a sweep without costing accuracy.
@@ -323,6 +326,7 @@ qt_handle_t* qt_create(int device, int n_qubits) {
     return nullptr;
   }
   h->own_stream = true;
+  if (const char* env = getenv("QTOMO_SKIP_SHOTS_CHECK")) h->check_shots = !(env[0] == '1');
   return h;
 }
 
@@ -889,12 +893,22 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     HIPCHK(h->hess.ensure((size_t)chunk * per_trial));
+    HIPCHK(h->ws_x.ensure(nel * sizeof(double)));
+    HIPCHK(h->ws_g.ensure(nel * sizeof(double)));
+    HIPCHK(h->ws_f.ensure((size_t)B * sizeof(double)));
+    HIPCHK(h->ws_act.ensure((size_t)B * sizeof(int32_t)));
+    double *wx = h->ws_x.as<double>(), *wg = h->ws_g.as<double>(), *wf = h->ws_f.as<double>();
+    int32_t* wact = h->ws_act.as<int32_t>();
+    // start point + first evaluation of every trial; then the BFGS loop of those that iterate, chunk by chunk
+    QT_LAUNCH_LARGE(qt::k_mle_large_start, B, h->M, h->prod.R1,
+                    (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
     for (int b0 = 0; b0 < B; b0 += chunk) {
       const int nb = (B - b0 < chunk) ? B - b0 : chunk;
-      QT_LAUNCH_LARGE_X(qt::k_mle_large, nb, h->M, h->prod.R1, max_iter,
-                        (h->view(), dc + (size_t)b0 * h->M, nb, init, max_iter, tol, drho + (size_t)b0 * h->D * 2,
+      QT_LAUNCH_LARGE_X(qt::k_mle_large_bfgs, nb, h->M, h->prod.R1, max_iter,
+                        (h->view(), dc + (size_t)b0 * h->M, nb, max_iter, tol, drho + (size_t)b0 * h->D * 2,
                          dnit ? dnit + b0 : nullptr, dnfev ? dnfev + b0 : nullptr, dfun ? dfun + b0 : nullptr,
-                         dst ? dst + b0 : nullptr, h->hess.as<double>()));
+                         dst ? dst + b0 : nullptr, wx + (size_t)b0 * h->D, wg + (size_t)b0 * h->D, wf + b0, wact + b0,
+                         h->hess.as<double>()));
     }
   } else {
     // up to one resident wave per SIMD (1024 trial-waves) the single fused launch wins; beyond that the

@@ -74,6 +74,12 @@ int qt_sync(qt_handle_t* h);
  * the two streams itself.  Every call leaves the calling thread's current HIP device unchanged. */
 #define QT_STREAM_LEGACY ((void*)1)
 int qt_set_stream(qt_handle_t* h, void* hip_stream);
+/* Per-handle switches.  QT_OPT_SHOTS_CHECK (default 1): compare every trial's per-setting totals with the Ns of
+ * qt_set_povm (QT_TRIAL_SHOTS).  QT_OPT_MLE_FUSED_MAX_WAVES (default 1024): batches of up to this many trial-wavefronts
+ * (n <= 3) run the MLE as one launch with the BFGS inverse Hessian in registers; larger ones as a start launch plus a
+ * BFGS launch in two-loop form (0 = always the latter).  Both forms compute scipy's iterates. */
+enum qt_option { QT_OPT_SHOTS_CHECK = 1, QT_OPT_MLE_FUSED_MAX_WAVES = 2 };
+int qt_set_option(qt_handle_t* h, int option, double value);
 /* hipEvent timers on the handle's stream: begin, ..., end -> elapsed milliseconds */
 int qt_timer_begin(qt_handle_t* h);
 int qt_timer_end(qt_handle_t* h, double* elapsed_ms);

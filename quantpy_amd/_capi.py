@@ -12,6 +12,7 @@ QT_DEVICE_PTR = 1
 QT_INIT_LIN = 0
 QT_INIT_MIXED = 1
 QT_STREAM_LEGACY = 1  # qt_set_stream: the legacy default ("null") stream
+QT_OPT_SHOTS_CHECK, QT_OPT_MLE_FUSED_MAX_WAVES = 1, 2  # qt_set_option
 
 # status codes (include/qtomo.h)
 QT_ERR_ARG, QT_ERR_STATE, QT_ERR_HIP, QT_ERR_SINGULAR, QT_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
@@ -30,6 +31,7 @@ SIGNATURES = {
     "qt_destroy": (None, [_vp]),
     "qt_sync": (_c_int, [_vp]),
     "qt_set_stream": (_c_int, [_vp, _vp]),
+    "qt_set_option": (_c_int, [_vp, _c_int, _c_dbl]),
     "qt_timer_begin": (_c_int, [_vp]),
     "qt_timer_end": (_c_int, [_vp, ctypes.POINTER(_c_dbl)]),
     "qt_pauli_basis": (_c_int, [_vp, _vp, _c_int]),

@@ -347,7 +347,10 @@ struct Large {
     __syncthreads();
     for (int k = 0; k < d; ++k) {
       const double akk = A[k * LD + k].re;
-      if (!(akk > 0.0)) ok = 0;
+      if (!(akk > 0.0)) {  // not positive definite: nobody reads the rest of the factor (uniform: every thread sees a_kk)
+        ok = 0;
+        break;
+      }
       const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
       const cd aik = A[i * LD + k], ajk = A[j * LD + k];
       const cd lik{aik.re * rs, aik.im * rs}, ljk{ajk.re * rs, ajk.im * rs};

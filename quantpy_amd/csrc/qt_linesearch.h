@@ -176,12 +176,15 @@ struct LineSearch {
       } else if (stp_ > stx_) stpf = stpmax;
       else stpf = stpmin;
     }
-    if (fp > fx_) {
-      sty_ = stp_; fy_ = fp; dy_ = dp;
-    } else {
-      if (sgnd < 0.0) { sty_ = stx_; fy_ = fx_; dy_ = dx_; }
-      stx_ = stp_; fx_ = fp; dx_ = dp;
-    }
+    // interval update, written as value selects + unconditional assignments: as conditional stores through the
+    // reference parameters the optimiser turned them into stores to a SELECTED address, i.e. scratch memory
+    const bool hi = fp > fx_;
+    const bool cross = !hi && sgnd < 0.0;
+    const double n_sty = hi ? stp_ : (cross ? stx_ : sty_), n_fy = hi ? fp : (cross ? fx_ : fy_),
+                 n_dy = hi ? dp : (cross ? dx_ : dy_);
+    const double n_stx = hi ? stx_ : stp_, n_fx = hi ? fx_ : fp, n_dx = hi ? dx_ : dp;
+    sty_ = n_sty; fy_ = n_fy; dy_ = n_dy;
+    stx_ = n_stx; fx_ = n_fx; dx_ = n_dx;
     stp_ = stpf;
   }
 
@@ -208,16 +211,34 @@ struct LineSearch {
     if (f <= ftest && fabs(g) <= C2 * -derphi0) return LS_ACCEPT;  // convergence overrides a warning
     if (warn) return LS_FAIL;
 
-    if (stage == 1 && f <= fx && f > ftest) {
-      double fm = f - stp * gtest, fxm = fx - stx * gtest, fym = fy - sty * gtest;
-      double gm = g - gtest, gxm = gx - gtest, gym = gy - gtest;
-      dcstep(stx, fxm, gxm, sty, fym, gym, stp, fm, gm, brackt, stmin, stmax);
-      fx = fxm + stx * gtest;
-      fy = fym + sty * gtest;
-      gx = gxm + gtest;
-      gy = gym + gtest;
+    // ONE call site of dcstep, on local copies: with two call sites (modified / plain function values) the
+    // optimiser merged them into one body fed by SELECTED ADDRESSES, which pinned nine doubles of this struct to
+    // scratch memory (72 bytes per lane in every BFGS kernel).  Same arithmetic, same order.
+    const bool modified = stage == 1 && f <= fx && f > ftest;
+    double sx = stx, sy = sty, fxe = fx, gxe = gx, fye = fy, gye = gy, fe = f, ge = g;
+    int br = brackt;
+    if (modified) {
+      fe = f - stp * gtest;
+      fxe = fx - stx * gtest;
+      fye = fy - sty * gtest;
+      ge = g - gtest;
+      gxe = gx - gtest;
+      gye = gy - gtest;
+    }
+    dcstep(sx, fxe, gxe, sy, fye, gye, stp, fe, ge, br, stmin, stmax);
+    stx = sx;
+    sty = sy;
+    brackt = br;
+    if (modified) {
+      fx = fxe + stx * gtest;
+      fy = fye + sty * gtest;
+      gx = gxe + gtest;
+      gy = gye + gtest;
     } else {
-      dcstep(stx, fx, gx, sty, fy, gy, stp, f, g, brackt, stmin, stmax);
+      fx = fxe;
+      fy = fye;
+      gx = gxe;
+      gy = gye;
     }
     if (brackt) {
       if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);

@@ -284,6 +284,7 @@ struct PovmView {
   const double* Ns = nullptr;  // [S]
   int S = 0, K = 0;
   double ns_tot = 0.0;
+  int extra = 0;  // extra doubles of per-trial LDS behind the scratch (k_mle_bfgs: line-search state + two-loop scalars)
 };
 
 // t_s / total == N_s / ns_tot, compared as cross products of integer-valued doubles (exact below 2^53; a few
@@ -342,8 +343,8 @@ struct Small {
   __host__ __device__ static int table_doubles(int M, int R1) {
     return R1 > 0 ? ((table_ints(M, R1) / 2 + M + 1) & ~1) : 0;  // index tables, then the row weights wrowR[M]; even
   }
-  __host__ __device__ static size_t lds_bytes(int M, int R1 = 0) {
-    return ((size_t)image_doubles(M) + table_doubles(M, R1) + (size_t)TPB * trial_doubles(M, R1)) * sizeof(double);
+  __host__ __device__ static size_t lds_bytes(int M, int R1 = 0, int extra = 0) {
+    return ((size_t)image_doubles(M) + table_doubles(M, R1) + (size_t)TPB * (trial_doubles(M, R1) + extra)) * sizeof(double);
   }
 
   // ---- per-lane context ---------------------------------------------------------------
@@ -372,6 +373,7 @@ struct Small {
     __device__ __forceinline__ double* tabT() const { return sm + oM + 3 * Mp; }               // [R1][4]
     __device__ __forceinline__ double* tabP() const { return sm + oM + 3 * Mp + 4 * pv.pr.R1; }  // [R1][4]
     __device__ __forceinline__ bool prod() const { return pv.pr.enabled != 0; }
+    __device__ __forceinline__ double* extra() const { return sm + trial_doubles(M, pv.pr.enabled ? pv.pr.R1 : 0); }  // [pv.extra]
   };
 
   // Trial handled by this lane's group; *live = false for the padding groups of the last block.
@@ -410,7 +412,7 @@ struct Small {
       }
       __syncthreads();
     }
-    c.sm = smem_block + image_doubles(pv.M) + table_doubles(pv.M, r1) + slot * trial_doubles(pv.M, r1);
+    c.sm = smem_block + image_doubles(pv.M) + table_doubles(pv.M, r1) + slot * (trial_doubles(pv.M, r1) + pv.extra);
     int xm = 0, zm = 0, ny = 0;
 #pragma unroll
     for (int b = 0; b < NQ; ++b) {
@@ -1454,13 +1456,134 @@ __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx
   }
 }
 
+// The same iterations WITHOUT the inverse Hessian in registers, for batches that fill the chip (k_mle_bfgs): with
+// H_0 = I the matrix scipy updates, H <- (I - rho s y^T) H (I - rho y s^T) + rho s s^T, is exactly the product form
+// the two-loop recursion evaluates, so p = -H_k g is computed from the (s_i, y_i) pairs of the accepted steps (the
+// n = 4, 5 kernels have always done this, qt_large.h).  Lane l only ever touches element l of each pair: private,
+// coalesced streams in a global workspace `pairs` [B][max_iter][2][D] that stay in L2; rho_i, alpha_i and -- across
+// every evaluation -- the line-search state live in the trial's LDS (`pv.extra` doubles).  Registers: ~150 instead
+// of 256 + 91 AGPRs, i.e. three waves per SIMD instead of one, and 2 k reductions + 4 k FMAs per iteration instead
+// of two 64-term products and a 64-entry rank-two update.  Same iterates as the dense form to rounding
+// (tests/test_gpu_state.py runs the reference's 70 golden trials through both).
 template <int NQ, bool ALDS>
-__global__ void __launch_bounds__(256) k_mle_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B, int max_iter,
+__device__ __forceinline__ void bfgs_iterate_2l(const typename Small<NQ, ALDS>::Ctx& c, bool mine, double xk, double gk,
+                                                double fk, int b, int max_iter, double gtol, double* __restrict__ rho,
+                                                int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
+                                                double* __restrict__ fun_out, int32_t* __restrict__ status_out,
+                                                double* __restrict__ pairs) {
+  using S = Small<NQ, ALDS>;
+  constexpr int D = S::D, G = S::G;
+  bool active = mine;
+  double* my = pairs + (size_t)b * max_iter * 2 * D + c.l;  // s_i[l] at my[2 i D], y_i[l] at my[(2 i + 1) D]
+  double* lsb = c.extra();                                  // [LineSearch::SLOTS]
+  double* prho = lsb + LineSearch::SLOTS;                   // [max_iter]
+  double* palpha = prho + max_iter;                         // [max_iter]
+  double old_old = fk + sqrt(gsum<G>(gk * gk)) / 2.0;
+  double pk = -gk, stp = 0.0;  // H0 = I
+  int kiter = 0, nfev = 1, status = 0;
+  // The line-search state lives IN LDS (every lane of the group reads and writes the same words with the same values):
+  // as a register-resident struct its ~35 doubles plus the temporaries of dcstep made the allocation 240 VGPRs.
+  static_assert(sizeof(LineSearch) <= LineSearch::SLOTS * sizeof(double), "LDS slot of the line-search state");
+  LineSearch& ls = *reinterpret_cast<LineSearch*>(lsb);
+  ls.start(fk, old_old, gsum<G>(gk * pk), &stp);
+  wave_sync();
+  const int eval_cap = (max_iter + 2) * 130;  // hard stop: every wave leaves the loop
+  while (__any(active)) {  // per wave: the waves of a workgroup do not synchronise here
+    double ft, gt;
+    S::nll_grad(c, xk + stp * pk, ft, gt);  // executed by the whole wave; finished trials idle through it
+    if (active && ++nfev > eval_cap) {
+      status = 2;
+      active = false;
+    }
+    if (active) {
+      const double dphi = gsum<G>(gt * pk);
+      double next = stp;
+      const int r = ls.advance(stp, ft, dphi, &next);
+      if (r == LS_EVAL) {
+        stp = next;
+      } else if (r == LS_FAIL) {
+        status = 2;
+        active = false;
+      } else {
+        const double sk = stp * pk;
+        const double pnorm2 = gsum<G>(pk * pk);
+        xk = xk + sk;
+        const double yk = gt - gk;
+        gk = gt;
+        old_old = fk;
+        fk = ft;
+        ++kiter;
+        const double gnorm = gmax<G>(fabs(gk));
+        if (!(gnorm > gtol)) {
+          active = false;
+        } else if (stp * sqrt(pnorm2) <= 0.0) {  // xrtol = 0 test
+          active = false;
+        } else if (!isfinite(fk)) {
+          status = 2;
+          active = false;
+        } else if (!(kiter < max_iter)) {
+          active = false;
+        } else {
+          const double ys = gsum<G>(yk * sk);
+          const double rhok = (ys == 0.0) ? 1000.0 : 1.0 / ys;
+          const int np = kiter - 1;  // index of the new pair
+          my[(size_t)(2 * np) * D] = sk;
+          my[(size_t)(2 * np + 1) * D] = yk;
+          if (c.l == 0) prho[np] = rhok;
+          wave_sync();
+          double q = gk;
+          for (int i = np; i >= 0; --i) {
+            const double si = (i == np) ? sk : my[(size_t)(2 * i) * D];
+            const double yi = (i == np) ? yk : my[(size_t)(2 * i + 1) * D];
+            const double a = prho[i] * gsum<G>(si * q);
+            if (c.l == 0) palpha[i] = a;
+            q = fma(-a, yi, q);
+          }
+          wave_sync();
+          for (int i = 0; i <= np; ++i) {
+            const double si = (i == np) ? sk : my[(size_t)(2 * i) * D];
+            const double yi = (i == np) ? yk : my[(size_t)(2 * i + 1) * D];
+            const double bb = prho[i] * gsum<G>(yi * q);
+            q = fma(si, palpha[i] - bb, q);
+          }
+          pk = -q;
+          ls.start(fk, old_old, gsum<G>(gk * pk), &stp);
+        }
+      }
+    }
+    wave_sync();
+  }
+  if (status == 0) {
+    const double gn = gmax<G>(fabs(gk));
+    const double xn = gmax<G>(fabs(xk));
+    if (kiter >= max_iter) status = 3;
+    else if (gn != gn || fk != fk || xn != xn) status = 4;
+  }
+  double tr;
+  const cd m = S::build_llh(c, xk, tr);
+  if (mine) {
+    double* out = rho + ((size_t)b * D + c.l) * 2;
+    out[0] = m.re / tr;
+    out[1] = m.im / tr;
+    if (c.l == 0) {
+      if (nit_out) nit_out[b] = kiter;
+      if (nfev_out) nfev_out[b] = nfev;
+      if (fun_out) fun_out[b] = fk;
+      if (status_out) status_out[b] = status;
+    }
+  }
+}
+
+#ifndef QT_BFGS_WAVES
+#define QT_BFGS_WAVES 3  // waves per SIMD the BFGS kernel is compiled for (3: <= 168 VGPRs)
+#endif
+template <int NQ, bool ALDS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QT_BFGS_WAVES))) k_mle_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B, int max_iter,
                                                   double gtol, double* __restrict__ rho, int32_t* __restrict__ nit_out,
                                                   int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,
                                                   int32_t* __restrict__ status_out, const double* __restrict__ ws_x,
                                                   const double* __restrict__ ws_g, const double* __restrict__ ws_f,
-                                                  const int32_t* __restrict__ ws_active) {
+                                                  const int32_t* __restrict__ ws_active, double* __restrict__ pairs) {
   using S = Small<NQ, ALDS>;
   constexpr int D = S::D;
   bool live;
@@ -1477,7 +1600,7 @@ __global__ void __launch_bounds__(256) k_mle_bfgs(PovmView pv, const int64_t* __
   const double xk = mine ? ws_x[(size_t)b * D + c.l] : (c.l < S::d ? 1.0 : 0.0);
   const double gk = mine ? ws_g[(size_t)b * D + c.l] : 0.0;
   const double fk = mine ? ws_f[b] : 0.0;
-  bfgs_iterate<NQ, ALDS>(c, mine, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out);
+  bfgs_iterate_2l<NQ, ALDS>(c, mine, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out, pairs);
 }
 
 // a10 in ONE launch, for batches small enough that its 256-VGPR footprint (two waves per SIMD) is no

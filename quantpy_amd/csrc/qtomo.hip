@@ -93,10 +93,12 @@ struct qt_handle {
   bool proc_set = false;
 
   double ns_tot = 0.0;  // sum of the registered shots per setting
-  bool check_shots = true;  // QTOMO_SKIP_SHOTS_CHECK=1 at qt_create turns the per-trial shots check off
+  bool check_shots = true;  // qt_set_option(QT_OPT_SHOTS_CHECK) / QTOMO_SKIP_SHOTS_CHECK=1 at qt_create
+  int fused_max_waves = 1024;  // qt_set_option(QT_OPT_MLE_FUSED_MAX_WAVES): largest batch (in trial-waves) of k_mle_fused
+  int lds_extra = 0;  // per-trial extra LDS doubles of the launch being prepared (k_mle_bfgs); 0 otherwise
   qt::PovmView view() const {
     return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod, jtol2,
-                        check_shots ? Ns.as<double>() : nullptr, S, K, ns_tot};
+                        check_shots ? Ns.as<double>() : nullptr, S, K, ns_tot, lds_extra};
   }
   // Jacobi stopping rule off^2 <= jtol2 * ||A||_F^2.  Measured on the C2 batch: the last sweep takes off^2
   // from > 1e-9 to < 1e-28 in one go, so no looser threshold saves a sweep without costing accuracy.
@@ -198,7 +200,7 @@ int allow_big_lds(K kernel, size_t bytes) {
 #define QT_LAUNCH_ONE(KERNEL, NQV, ALDSV, M_, B_, ARGS)                                                   \
   do {                                                                                                    \
     using S_ = qt::Small<NQV, ALDSV>;                                                                     \
-    const size_t lds_ = S_::lds_bytes(M_, h->prod.enabled ? h->prod.R1 : 0);                              \
+    const size_t lds_ = S_::lds_bytes(M_, h->prod.enabled ? h->prod.R1 : 0, h->lds_extra);                \
     if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for the n<=3 kernels (%zu B of LDS)", lds_); \
     if (int r_ = allow_big_lds(KERNEL<NQV, ALDSV>, lds_)) return r_;                                      \
     const int grid_ = ((B_) + S_::TPB - 1) / S_::TPB;                                                     \
@@ -364,6 +366,18 @@ int qt_set_stream(qt_handle_t* h, void* hip_stream) {
     h->own_stream = true;
   }
   return 0;
+}
+
+int qt_set_option(qt_handle_t* h, int option, double value) {
+  QT_ENTER(h);
+  switch (option) {
+    case QT_OPT_SHOTS_CHECK: h->check_shots = value != 0.0; return 0;
+    case QT_OPT_MLE_FUSED_MAX_WAVES:
+      if (!(value >= 0.0 && value <= 1048576.0)) return fail(QT_ERR_ARG, "QT_OPT_MLE_FUSED_MAX_WAVES out of range");
+      h->fused_max_waves = (int)value;
+      return 0;
+    default: return fail(QT_ERR_ARG, "unknown option %d", option);
+  }
 }
 
 int qt_timer_begin(qt_handle_t* h) {
@@ -914,9 +928,10 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
     // up to one resident wave per SIMD (1024 trial-waves) the single fused launch wins; beyond that the
     // 256-VGPR BFGS loop would cap occupancy for every trial, so the split pair is used
     const int waves = (B + (64 / h->D > 0 ? 64 / h->D : 1) - 1) / (64 / h->D > 0 ? 64 / h->D : 1);
-    if (waves <= 1024) {
+    if (waves <= h->fused_max_waves) {
       QT_LAUNCH_SMALL(qt::k_mle_fused, h->M, B, (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst));
     } else {
+      if (max_iter > 4096) return fail(QT_ERR_UNSUPPORTED, "max_iter > 4096 is not supported for batches above %d trial-waves", h->fused_max_waves);
       HIPCHK(h->ws_x.ensure(nel * sizeof(double)));
       HIPCHK(h->ws_g.ensure(nel * sizeof(double)));
       HIPCHK(h->ws_f.ensure((size_t)B * sizeof(double)));
@@ -925,8 +940,23 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
       int32_t* wact = h->ws_act.as<int32_t>();
       QT_LAUNCH_SMALL(qt::k_mle_start, h->M, B,
                       (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
-      QT_LAUNCH_SMALL(qt::k_mle_bfgs, h->M, B,
-                      (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+      // BFGS history of the trials that iterate: 2 D doubles per iteration and trial (two-loop recursion), in
+      // chunks of <= 4 GiB; rho_i, alpha_i and the parked line-search state in LDS
+      const size_t per_trial = (size_t)(max_iter > 0 ? max_iter : 1) * 2 * h->D * sizeof(double);
+      int chunk = (int)(((size_t)4 << 30) / per_trial);
+      if (chunk < 1) chunk = 1;
+      if (chunk > B) chunk = B;
+      HIPCHK(h->hess.ensure((size_t)chunk * per_trial));
+      h->lds_extra = qt::LineSearch::SLOTS + 2 * (max_iter > 0 ? max_iter : 1);
+      for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+        QT_LAUNCH_SMALL(qt::k_mle_bfgs, h->M, nb,
+                        (h->view(), dc + (size_t)b0 * h->M, nb, max_iter, tol, drho + (size_t)b0 * h->D * 2,
+                         dnit ? dnit + b0 : nullptr, dnfev ? dnfev + b0 : nullptr, dfun ? dfun + b0 : nullptr,
+                         dst ? dst + b0 : nullptr, wx + (size_t)b0 * h->D, wg + (size_t)b0 * h->D, wf + b0, wact + b0,
+                         h->hess.as<double>()));
+      }
+      h->lds_extra = 0;
     }
   }
   if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;

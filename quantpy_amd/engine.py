@@ -146,6 +146,11 @@ class Engine:
         if not self._stream_bound:
             self.bind_torch_stream()
 
+    def set_option(self, option, value):
+        """qt_set_option: _capi.QT_OPT_SHOTS_CHECK (0 / 1), _capi.QT_OPT_MLE_FUSED_MAX_WAVES (0 = always the split,
+        two-loop BFGS path)."""
+        self._chk(self.lib.qt_set_option(self._h, int(option), float(value)))
+
     def timer_begin(self):
         self._chk(self.lib.qt_timer_begin(self._h))
 

@@ -14,6 +14,7 @@ import quantpy_oracle as oracle  # noqa: E402  (checker only)
 import quantpy_amd as qp  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+split = len(sys.argv) > 2 and sys.argv[2] == "split"  # force k_mle_start + k_mle_bfgs (two-loop BFGS) for every batch
 rng = np.random.default_rng(2718)
 worst = dict(lin=0.0, mle_infid=0.0, nit_mismatch=0, status=0, total=0)
 for n in (1, 2, 3):
@@ -30,6 +31,7 @@ for n in (1, 2, 3):
                 counts = np.stack([oracle.sample_counts(povm, oracle.bloch_from_matrix(rho), shots) for _ in range(trials)])
                 eng = qp.get_engine(n)
                 eng.set_povm(qp.generate_measurement_matrix(povm_name, n), shots)
+                eng.set_option(2, 0 if split else 1024)  # QT_OPT_MLE_FUSED_MAX_WAVES
                 lin = eng.lin(counts, physical=True)
                 for init in ("lin", "mixed"):
                     got, info = eng.mle(counts, init=init, return_info=True)

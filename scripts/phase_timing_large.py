@@ -33,7 +33,7 @@ waves = (d * d) // 64
 prof = torch.zeros((B * waves + 8, 32), dtype=torch.int64, device="cuda")
 eng.lib.qt_debug_set_prof.argtypes = [ctypes.c_void_p]
 assert eng.lib.qt_debug_set_prof(prof.data_ptr()) == 0
-names = {1: "make_ctx (load)", 2: "lin_invert", 3: "cholesky #1", 6: "psd_project (Jacobi)", 7: "cholesky #2",
+names = {1: "make_ctx (load)", 2: "lin_invert", 3: "cholesky #1", 6: "psd_project (sign clip)", 7: "cholesky #2",
          8: "make_feasible end", 9: "nll_grad", 10: "BFGS + build + store", 11: "(nll) entry", 12: "(nll) build L L^H",
          13: "(nll) bloch_of", 14: "(nll) fwd stages 1..n-1", 15: "(nll) stage n + log", 16: "(nll) backward stages",
          17: "(nll) matrix_of", 18: "(nll) Gt L + tail"}
@@ -46,7 +46,7 @@ eng.mle_dev(cd_, out)
 ms = eng.timer_end()
 p = prof.cpu().numpy()[: B * waves: waves]
 nonpd = p[:, 6] > 0
-print(f"== k_mle_large<{n}>: {ms * 1e3:.1f} us for {B} trials; {nonpd.sum()} non-PD")
+print(f"== k_mle_large_start<{n}>: {ms * 1e3:.1f} us for {B} trials; {nonpd.sum()} non-PD")
 for label, sel in (("PD", ~nonpd), ("non-PD", nonpd)):
     if not sel.any():
         continue

@@ -155,10 +155,15 @@ def test_cholesky_param_and_nll_golden(oracle):
     assert st == 1
 
 
-def test_mle_all_golden_trials(oracle):
+@pytest.mark.parametrize("path", ["fused (inverse Hessian in registers)", "split (two-loop recursion)"])
+def test_mle_all_golden_trials(oracle, path):
     """70 reference trials (full-rank / rank-1 / rank-2 / GHZ / |0..0> / mixed; 100, 1e3, 1e5
     shots; init lin / mixed; three POVMs): same BFGS iteration count as the reference, state
-    fidelity within 1e-6 (north_star), and evaluation counts that reproduce scipy's nfev."""
+    fidelity within 1e-6 (north_star), and evaluation counts that reproduce scipy's nfev --
+    through both forms of the BFGS kernel (small batches: k_mle_fused; batches that fill the chip:
+    k_mle_start + k_mle_bfgs, forced here with QT_OPT_MLE_FUSED_MAX_WAVES = 0)."""
+    from quantpy_amd import _capi
+
     g = load_golden("mle")
     worst = 0.0
     for k in range(int(g["n_mle_cases"])):
@@ -168,7 +173,11 @@ def test_mle_all_golden_trials(oracle):
         counts = g[key + "_counts"]
         a = oracle.measurement_matrix(str(g[key + "_povm"]), n)
         eng.set_povm(a, counts.sum(-1))
-        rho, info = eng.mle(counts, init=str(g[key + "_init"]), return_info=True)
+        eng.set_option(_capi.QT_OPT_MLE_FUSED_MAX_WAVES, 0 if path.startswith("split") else 1024)
+        try:
+            rho, info = eng.mle(counts, init=str(g[key + "_init"]), return_info=True)
+        finally:
+            eng.set_option(_capi.QT_OPT_MLE_FUSED_MAX_WAVES, 1024)
         infid = abs(oracle.infidelity(g[key + "_rho"], rho))
         worst = max(worst, infid)
         assert info["status"] == 0, key

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "qt_jacobi_wg.h"
+#include "qt_signclip_wg.h"
 #include "qt_ops.h"    // v4f64
 #include "qt_small.h"  // gsum
 
@@ -102,6 +103,7 @@ struct ProcWG {
   // barrier per round) in its own LDS block `jac`; DC = 4 (16 active threads of one wavefront) keeps the small
   // round-robin version below with the v* / r* / o* arrays.
   static constexpr bool kWgJacobi = DC == 16;
+  static constexpr bool kSignClipCP = true;  // false: the workgroup Jacobi eigensolver (the version before round 2)
   using JW = JacobiWG<kWgJacobi ? DC : 16, kWgJacobi ? NE : 256, false>;
   static constexpr int oJimg0 = 0, oJimg1 = oJimg0 + 2 * NE, oJrot = oJimg1 + 2 * NE, oJv = oJrot + 6 * DC,
                        oJlam = oJv + 2 * DC * (DC + 1), oJred = oJlam + DC, kJacDoubles = oJred + 32;
@@ -194,7 +196,18 @@ struct ProcWG {
         return;
       }
     }
-    if constexpr (kWgJacobi) {
+    if constexpr (kWgJacobi && kSignClipCP) {
+      // eigenvalue clip through the matrix sign function on the FP64 matrix cores (qt_signclip_wg.h): three 16 x 17
+      // complex images + reduction scratch inside the `jac` block
+      using SC = SignClipWG<DC, NE>;
+      static_assert(3 * 2 * DC * SC::P + 32 <= kJacDoubles, "the sign-clip images fit the Jacobi block");
+      const typename SC::Lds o{0, 2 * DC * SC::P, 4 * DC * SC::P, 6 * DC * SC::P};
+      const cd out = SC::clip(threadIdx.x, cd{ar, ai}, eps, sh.jac, o, false);
+      __syncthreads();
+      re = out.re;
+      im = out.im;
+      return;
+    } else if constexpr (kWgJacobi) {
       const typename JW::Lds o{oJimg0, oJimg1, oJrot, oJv, oJlam, oJred};
       const cd out = JW::clip(threadIdx.x, cd{ar, ai}, eps, sh.jac, o, false, warm && *warm);
       if (warm) *warm = true;

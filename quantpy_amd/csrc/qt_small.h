@@ -555,12 +555,13 @@ struct Small {
     const int l = (threadIdx.x & 63) % G, M = pv.M, K = pv.K;
     pf.ok = M <= 4 * G;
     pf.seg = pf.ok && pv.Ns && (K == 2 || K == 4 || K == 8 || K == 16) && G % K == 0;
-    if (pf.ok) {
+    const int lgk = __builtin_ctz((unsigned)(K > 0 ? K : 1));  // K is a power of two on the seg path: m / K is a shift
+    if (pf.ok) {                                               // (a 32-bit division by a run-time K is ~25 instructions)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int m = l + q * G;
         pf.v[q] = counts[m < M ? m : M - 1];
-        if (pf.seg) pf.ns[q] = pv.Ns[(m < M ? m : M - 1) / K];
+        if (pf.seg) pf.ns[q] = pv.Ns[(m < M ? m : M - 1) >> lgk];
       }
     }
     if (!pf.seg) pf.ns[0] = pv.Ns ? pv.Ns[l < pv.S ? l : pv.S - 1] : 0.0;
@@ -1575,7 +1576,8 @@ __device__ __forceinline__ void bfgs_iterate_2l(const typename Small<NQ, ALDS>::
 }
 
 #ifndef QT_BFGS_WAVES
-#define QT_BFGS_WAVES 3  // waves per SIMD the BFGS kernel is compiled for (3: <= 168 VGPRs)
+#define QT_BFGS_WAVES 2  // waves per SIMD the BFGS kernel is compiled for; measured at B = 65 536 (15-iteration trials): 3 waves
+                         // (<= 168 VGPRs, 18 spilled) 5.29 ms, 2 waves (205 VGPRs, no scratch) 5.39 ms -- instruction-bound either way
 #endif
 template <int NQ, bool ALDS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QT_BFGS_WAVES))) k_mle_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B, int max_iter,
@@ -1600,7 +1602,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QT_BFG
   const double xk = mine ? ws_x[(size_t)b * D + c.l] : (c.l < S::d ? 1.0 : 0.0);
   const double gk = mine ? ws_g[(size_t)b * D + c.l] : 0.0;
   const double fk = mine ? ws_f[b] : 0.0;
-  bfgs_iterate_2l<NQ, ALDS>(c, mine, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out, pairs);
+  // n = 3: two-loop form (the 64 x 64 inverse Hessian would cost 128 VGPRs per lane); n = 1, 2: H is 4 / 16 doubles
+  // per lane and stays in registers
+  if constexpr (NQ == 3)
+    bfgs_iterate_2l<NQ, ALDS>(c, mine, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out, pairs);
+  else
+    bfgs_iterate<NQ, ALDS>(c, mine, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out);
 }
 
 // a10 in ONE launch, for batches small enough that its 256-VGPR footprint (two waves per SIMD) is no

@@ -942,12 +942,15 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
                       (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
       // BFGS history of the trials that iterate: 2 D doubles per iteration and trial (two-loop recursion), in
       // chunks of <= 4 GiB; rho_i, alpha_i and the parked line-search state in LDS
-      const size_t per_trial = (size_t)(max_iter > 0 ? max_iter : 1) * 2 * h->D * sizeof(double);
-      int chunk = (int)(((size_t)4 << 30) / per_trial);
-      if (chunk < 1) chunk = 1;
-      if (chunk > B) chunk = B;
-      HIPCHK(h->hess.ensure((size_t)chunk * per_trial));
-      h->lds_extra = qt::LineSearch::SLOTS + 2 * (max_iter > 0 ? max_iter : 1);
+      int chunk = B;
+      if (h->nq == 3) {  // (n = 1, 2 keep the 4 / 16-entry Hessian rows in registers: no workspace)
+        const size_t per_trial = (size_t)(max_iter > 0 ? max_iter : 1) * 2 * h->D * sizeof(double);
+        chunk = (int)(((size_t)4 << 30) / per_trial);
+        if (chunk < 1) chunk = 1;
+        if (chunk > B) chunk = B;
+        HIPCHK(h->hess.ensure((size_t)chunk * per_trial));
+        h->lds_extra = qt::LineSearch::SLOTS + 2 * (max_iter > 0 ? max_iter : 1);
+      }
       for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (B - b0 < chunk) ? B - b0 : chunk;
         QT_LAUNCH_SMALL(qt::k_mle_bfgs, h->M, nb,

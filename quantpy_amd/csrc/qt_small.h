@@ -316,10 +316,10 @@ struct Small {
   static constexpr int oV = oB + MAT;      // complex [d][LD]
   static constexpr int oVec = oV + MAT;    // [D] + one slot that always holds 0 (source of L's zero entries)
   static constexpr int oLam = oVec + D + 2;  // [d] (+ pad to even)
-  static constexpr int oM = oLam + 2 * ((d + 1) / 2);  // rbuf[Mp], freq[Mp], bufB[Mp], tables[8 R1]
+  static constexpr int oM = oLam + 2 * ((d + 1) / 2);  // rbuf[Mp], freq[Mp], bufB[Mp]
   __host__ __device__ static int trial_doubles(int M, int R1 = 0) {
     const int Mp = (M + 1) & ~1;
-    return oM + (R1 > 0 ? 3 : 2) * Mp + 8 * R1;
+    return oM + (R1 > 0 ? 3 : 2) * Mp;
   }
   __host__ __device__ static int image_doubles(int M) { return ALDS ? ((M * LDA + 1) & ~1) : 0; }
   // Index tables of a product POVM, staged once per workgroup (shared by its waves): forward stage
@@ -341,7 +341,10 @@ struct Small {
   }
   __host__ __device__ static int table_ints(int M, int R1) { return (fwd_ints(R1) + bwd_ints(R1) + M + 1) & ~1; }
   __host__ __device__ static int table_doubles(int M, int R1) {
-    return R1 > 0 ? ((table_ints(M, R1) / 2 + M + 1) & ~1) : 0;  // index tables, then the row weights wrowR[M]; even
+    // index tables, then the row weights wrowR[M] (padded to even), then the one-qubit tables T and pinv(T)^T
+    // ([R1][4] each, 16-byte aligned): staged ONCE per workgroup.  (The one-qubit tables used to be copied per trial
+    // inside load_freq: two dependent global loads on the critical path of a lone wave, ~1 us of the 16 us step.)
+    return R1 > 0 ? (table_ints(M, R1) / 2 + ((M + 1) & ~1) + 8 * R1) : 0;
   }
   __host__ __device__ static size_t lds_bytes(int M, int R1 = 0, int extra = 0) {
     return ((size_t)image_doubles(M) + table_doubles(M, R1) + (size_t)TPB * (trial_doubles(M, R1) + extra)) * sizeof(double);
@@ -354,6 +357,7 @@ struct Small {
     double* img;     // the workgroup's operand image (ALDS)
     const int *tfwd, *tbwd, *trmap;  // the workgroup's copy of the product-POVM index tables (LDS)
     const double* twrow;             // ... and of the row weights N_s / sum(N), R-order
+    const double *ttab, *ptab;       // ... and of the one-qubit tables T [R1][4], pinv(T)^T [R1][4]
     int M, Mp;
     PovmView pv;
     // Pauli string k = l:  P_k[r][r ^ xm] = (-i)^ny (-1)^popc(r & zm)
@@ -370,8 +374,8 @@ struct Small {
     __device__ __forceinline__ double* rbuf() const { return sm + oM; }
     __device__ __forceinline__ double* freq() const { return sm + oM + Mp; }
     __device__ __forceinline__ double* bufB() const { return sm + oM + 2 * Mp; }
-    __device__ __forceinline__ double* tabT() const { return sm + oM + 3 * Mp; }               // [R1][4]
-    __device__ __forceinline__ double* tabP() const { return sm + oM + 3 * Mp + 4 * pv.pr.R1; }  // [R1][4]
+    __device__ __forceinline__ const double* tabT() const { return ttab; }  // [R1][4]
+    __device__ __forceinline__ const double* tabP() const { return ptab; }  // [R1][4]
     __device__ __forceinline__ bool prod() const { return pv.pr.enabled != 0; }
     __device__ __forceinline__ double* extra() const { return sm + trial_doubles(M, pv.pr.enabled ? pv.pr.R1 : 0); }  // [pv.extra]
   };
@@ -401,9 +405,16 @@ struct Small {
     c.tbwd = tabs + fwd_ints(r1);
     c.trmap = c.tbwd + bwd_ints(r1);
     double* wrow = smem_block + image_doubles(pv.M) + table_ints(pv.M, r1) / 2;
+    double* t1 = wrow + ((pv.M + 1) & ~1);
     c.twrow = wrow;
+    c.ttab = t1;
+    c.ptab = t1 + 4 * r1;
     if (r1 > 0) {  // every thread of the workgroup comes through here once, before anything else
       const int nf = fwd_ints(r1), nb = bwd_ints(r1);
+      for (int e = threadIdx.x; e < 4 * r1; e += NT) {
+        t1[e] = pv.pr.T[e];
+        t1[4 * r1 + e] = pv.pr.P1T[e];
+      }
       for (int e = threadIdx.x; e < nf; e += NT) tabs[e] = pv.pr.fwd[e];
       for (int e = threadIdx.x; e < nb; e += NT) tabs[nf + e] = pv.pr.bwd[e];
       for (int e = threadIdx.x; e < pv.M; e += NT) {
@@ -594,12 +605,6 @@ struct Small {
         const double v = (double)counts[m];
         raw[m] = v;
         part += v;
-      }
-    }
-    if (c.prod()) {
-      for (int e = c.l; e < 4 * c.pv.pr.R1; e += G) {
-        c.tabT()[e] = c.pv.pr.T[e];
-        c.tabP()[e] = c.pv.pr.P1T[e];
       }
     }
     const double total = gsum<G>(part);
@@ -978,7 +983,9 @@ struct Small {
     QT_STAMP(3);
     const double tr = gsum<G>(c.i == c.j ? r.re : 0.0);
     cd out{r.re / tr, r.im / tr};
-    const double rst = 1.0 / sqrt(tr);
+    // 1 / sqrt(tr) for the Cholesky parameters of r / tr: hardware seed + Newton (~1 ulp) instead of an IEEE sqrt and
+    // an IEEE division (~60 instructions on the critical path); tr = 1 up to the noise of the linear inversion
+    const double rst = tr > 0.0 ? fast_rsqrt(tr) : 1.0 / sqrt(tr);
     x = x * rst;  // L of r/tr
     double lscale = rst;  // Bm() holds the factor of r, not of r/tr
     if (!__all(ok)) {
@@ -1466,7 +1473,9 @@ __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx
 // of 256 + 91 AGPRs, i.e. three waves per SIMD instead of one, and 2 k reductions + 4 k FMAs per iteration instead
 // of two 64-term products and a 64-entry rank-two update.  Same iterates as the dense form to rounding
 // (tests/test_gpu_state.py runs the reference's 70 golden trials through both).
-template <int NQ, bool ALDS>
+// LP > 0 (k_mle_fused: one workgroup per CU, LDS to spare): the first LP pairs stay in the trial's LDS and only later
+// ones go to the global workspace -- a lone wave would otherwise wait out an L2 round trip per block of pairs.
+template <int NQ, bool ALDS, int LP = 0>
 __device__ __forceinline__ void bfgs_iterate_2l(const typename Small<NQ, ALDS>::Ctx& c, bool mine, double xk, double gk,
                                                 double fk, int b, int max_iter, double gtol, double* __restrict__ rho,
                                                 int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
@@ -1479,6 +1488,7 @@ __device__ __forceinline__ void bfgs_iterate_2l(const typename Small<NQ, ALDS>::
   double* lsb = c.extra();                                  // [LineSearch::SLOTS]
   double* prho = lsb + LineSearch::SLOTS;                   // [max_iter]
   double* palpha = prho + max_iter;                         // [max_iter]
+  double* lp = palpha + max_iter + c.l;                     // [LP][2][D]: s_i[l] at lp[2 i D], y_i[l] at lp[(2 i + 1) D]
   double old_old = fk + sqrt(gsum<G>(gk * gk)) / 2.0;
   double pk = -gk, stp = 0.0;  // H0 = I
   int kiter = 0, nfev = 1, status = 0;
@@ -1528,22 +1538,43 @@ __device__ __forceinline__ void bfgs_iterate_2l(const typename Small<NQ, ALDS>::
           const double ys = gsum<G>(yk * sk);
           const double rhok = (ys == 0.0) ? 1000.0 : 1.0 / ys;
           const int np = kiter - 1;  // index of the new pair
-          my[(size_t)(2 * np) * D] = sk;
-          my[(size_t)(2 * np + 1) * D] = yk;
+          if (np < LP) {
+            lp[(2 * np) * D] = sk;
+            lp[(2 * np + 1) * D] = yk;
+          } else {
+            my[(size_t)(2 * np) * D] = sk;
+            my[(size_t)(2 * np + 1) * D] = yk;
+          }
           if (c.l == 0) prho[np] = rhok;
           wave_sync();
           double q = gk;
           for (int i = np; i >= 0; --i) {
-            const double si = (i == np) ? sk : my[(size_t)(2 * i) * D];
-            const double yi = (i == np) ? yk : my[(size_t)(2 * i + 1) * D];
+            double si = sk, yi = yk;
+            if (i != np) {
+              if (i < LP) {
+                si = lp[(2 * i) * D];
+                yi = lp[(2 * i + 1) * D];
+              } else {
+                si = my[(size_t)(2 * i) * D];
+                yi = my[(size_t)(2 * i + 1) * D];
+              }
+            }
             const double a = prho[i] * gsum<G>(si * q);
             if (c.l == 0) palpha[i] = a;
             q = fma(-a, yi, q);
           }
           wave_sync();
           for (int i = 0; i <= np; ++i) {
-            const double si = (i == np) ? sk : my[(size_t)(2 * i) * D];
-            const double yi = (i == np) ? yk : my[(size_t)(2 * i + 1) * D];
+            double si = sk, yi = yk;
+            if (i != np) {
+              if (i < LP) {
+                si = lp[(2 * i) * D];
+                yi = lp[(2 * i + 1) * D];
+              } else {
+                si = my[(size_t)(2 * i) * D];
+                yi = my[(size_t)(2 * i + 1) * D];
+              }
+            }
             const double bb = prho[i] * gsum<G>(yi * q);
             q = fma(si, palpha[i] - bb, q);
           }
@@ -1610,6 +1641,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QT_BFG
     bfgs_iterate<NQ, ALDS>(c, mine, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out);
 }
 
+constexpr int kFusedLdsPairs = 24;  // (s, y) pairs of k_mle_fused<3> kept in LDS: 24 KB per trial, 4 trials per workgroup
+
 // a10 in ONE launch, for batches small enough that its 256-VGPR footprint (two waves per SIMD) is no
 // handicap: start point, first evaluation and -- for the waves that still hold an open trial -- the BFGS
 // loop.  Saves the second launch (2.5-4 us when nothing iterates, ~10 % of a 1000-trial step).
@@ -1617,7 +1650,8 @@ template <int NQ, bool ALDS>
 __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* __restrict__ counts, int B, int init,
                                                    int max_iter, double gtol, double* __restrict__ rho,
                                                    int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
-                                                   double* __restrict__ fun_out, int32_t* __restrict__ status_out) {
+                                                   double* __restrict__ fun_out, int32_t* __restrict__ status_out,
+                                                   double* __restrict__ pairs) {
   using S = Small<NQ, ALDS>;
   constexpr int D = S::D, G = S::G, d = S::d;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1682,7 +1716,13 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
     gk = 0.0;
     fk = 0.0;
   }
-  bfgs_iterate<NQ, ALDS>(c, iterate, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out);
+  // n = 3: two-loop form, the first kFusedLdsPairs (s, y) pairs in LDS (the 64 x 64 inverse Hessian took 128 VGPRs per lane
+  // and ~460 AGPR moves per iteration); n = 1, 2: the 4 / 16-entry Hessian rows stay in registers
+  if constexpr (NQ == 3)
+    bfgs_iterate_2l<NQ, ALDS, kFusedLdsPairs>(c, iterate, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out,
+                                              status_out, pairs);
+  else
+    bfgs_iterate<NQ, ALDS>(c, iterate, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out);
 }
 
 // Metropolis-Hastings chain on the Cholesky parameters (reference mhmc.py:80-119 with

@@ -933,10 +933,21 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
     // up to one resident wave per SIMD (1024 trial-waves) the single fused launch wins; beyond that the
     // 256-VGPR BFGS loop would cap occupancy for every trial, so the split pair is used
     const int waves = (B + (64 / h->D > 0 ? 64 / h->D : 1) - 1) / (64 / h->D > 0 ? 64 / h->D : 1);
-    if (waves <= h->fused_max_waves) {
-      QT_LAUNCH_SMALL(qt::k_mle_fused, h->M, B, (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst));
+    // n = 3 keeps rho_i / alpha_i of every BFGS iteration in the trial's LDS (16 bytes per iteration and trial):
+    // the one-launch kernel (which also keeps 24 pairs there) up to 256 iterations, the split pair up to 2000
+    if (h->nq == 3 && max_iter > 2000)
+      return fail(QT_ERR_UNSUPPORTED, "max_iter > 2000 is not supported for n_qubits = 3 (LDS holds the two-loop scalars)");
+    if (waves <= h->fused_max_waves && !(h->nq == 3 && max_iter > 256)) {
+      if (h->nq == 3) {  // two-loop BFGS: line-search state, rho_i, alpha_i and the first pairs in LDS, later pairs in global
+        const int mi = max_iter > 0 ? max_iter : 1;
+        h->lds_extra = qt::LineSearch::SLOTS + 2 * mi + qt::kFusedLdsPairs * 2 * h->D;
+        const int over = mi > qt::kFusedLdsPairs ? mi : 1;  // (indexed by pair number: rows below kFusedLdsPairs stay unused)
+        HIPCHK(h->hess.ensure((size_t)B * over * 2 * h->D * sizeof(double)));
+      }
+      QT_LAUNCH_SMALL(qt::k_mle_fused, h->M, B,
+                      (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, h->hess.as<double>()));
+      h->lds_extra = 0;
     } else {
-      if (max_iter > 4096) return fail(QT_ERR_UNSUPPORTED, "max_iter > 4096 is not supported for batches above %d trial-waves", h->fused_max_waves);
       HIPCHK(h->ws_x.ensure(nel * sizeof(double)));
       HIPCHK(h->ws_g.ensure(nel * sizeof(double)));
       HIPCHK(h->ws_f.ensure((size_t)B * sizeof(double)));

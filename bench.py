@@ -17,7 +17,7 @@ before anything in this process has touched the GPU.  Each rank reconstructs its
   "configs4_weak"     5-qubit MLE (configs[4]), 256 trials per rank, weak-scaled;
   "bootstrap_ci"      the 2000-resample bootstrap CI of configs[3], strong-scaled, ONE all-gather;
   "bootstrap_ci_n5"   the same for 5 qubits (2000 resamples), strong-scaled;
-  "bootstrap_ci_large" 262 144 resamples at n = 3 (a size where sharding matters), strong-scaled.
+  "bootstrap_ci_large" 2 097 152 resamples at n = 3 (a size where sharding matters), strong-scaled.
 
 Rank 0 prints ONE JSON line (contract in the task statement) that also carries
   "roofline":     the dominant kernel against the HBM roofline, from HIP-event timing of
@@ -140,7 +140,8 @@ def main():
     ap.add_argument("--cpu-per-core", type=int, default=1500,
                     help="reconstructions per worker in the all-cores CPU baseline; 0 = skip it")
     ap.add_argument("--bootstrap-points", type=int, default=2000)
-    ap.add_argument("--bootstrap-large", type=int, default=262144, help="resamples of the large n = 3 bootstrap leg; 0 = off")
+    ap.add_argument("--bootstrap-large", type=int, default=2097152,
+                    help="resamples of the large n = 3 bootstrap leg (a size at which 8 GPUs still have ~2 ms of work each); 0 = off")
     ap.add_argument("--saturation-batch", type=int, default=65536, help="extra (untimed-contract) measurement; 0 = off")
     ap.add_argument("--pipelined-steps", type=int, default=0,
                     help="extra: this many steps alternated over two streams (off by default so that a rocprofv3 pass over the "
@@ -481,8 +482,12 @@ def main():
         the full (n, S, K) host array (identical on every rank); `tile` repeats this rank's shard on the device."""
         n_tot = len(resamples) * tile
         lo, hi = qd.shard_bounds(n_tot)
-        idx = np.arange(lo, hi) % len(resamples)
-        shard = torch.from_numpy(np.ascontiguousarray(resamples[idx])).cuda()
+        if tile == 1:
+            shard = torch.from_numpy(np.ascontiguousarray(resamples[lo:hi])).cuda()
+        else:  # the distinct resamples go up once; this rank's slice of the tiled sequence is gathered on the device
+            pool_d = torch.from_numpy(np.ascontiguousarray(resamples)).cuda()
+            shard = pool_d[torch.arange(lo, hi, device="cuda") % len(resamples)].contiguous()
+            del pool_d
         rho_b = torch.empty((hi - lo, dd, dd), dtype=torch.complex128, device="cuda")
         dist_b = torch.empty(hi - lo, dtype=torch.float64, device="cuda")
         centre_d = torch.from_numpy(np.ascontiguousarray(centre_matrix)).cuda()

@@ -50,8 +50,9 @@ struct Large {
   static constexpr int oVec = oL + MAT;        // [D]
   static constexpr int oLam = oVec + D;        // [d]
   static constexpr int oRed = oLam + d;        // [32] reduction scratch
+  static constexpr bool kJacobiClip = false;   // a7 through the cyclic Jacobi eigensolver instead of the sign-function clip
   static constexpr int oRot = oRed + 32;       // Jacobi rotations of this round and the next: 2 x (cos [d], w [d] complex)
-  static constexpr int oLs = oRot + 6 * d;     // line-search state parked across an evaluation (LineSearch::SLOTS)
+  static constexpr int oLs = oRot + (kJacobiClip ? 6 * d : 0);  // line-search state parked across an evaluation
   static constexpr int oTab = oLs + LineSearch::SLOTS;  // tabT [R1][4], tabP [R1][4]
   __host__ __device__ static int x_doubles(int M) { return (M > MAT ? M : MAT) + (M & 1); }
   __host__ __device__ static int y_doubles(int M, int R1) {
@@ -70,6 +71,7 @@ struct Large {
     ProductView pr;
     const double *Aw, *AwT, *PinvT;  // dense operands ([M][D], [D][M], [M][D]); read only when the POVM is not a product
     const int64_t* counts;  // this trial's counts [M]
+    const uint32_t* cnt;    // LDS copy of the counts in R-order, or null (frequencies are re-read three times per MLE)
     double tot;             // sum of counts
     bool shots_ok;          // per-setting totals proportional to the registered shots (PovmView::Ns)
     int xm, zm, ny;
@@ -154,9 +156,22 @@ struct Large {
       c.tabP()[e] = c.pr.P1T[e];
     }
     double part = 0.0;
+    bool wide = false;
+    uint32_t* cache = nullptr;
+    // pv.extra > 0: offset (in doubles) of a 4 M-byte block behind everything else in the LDS allocation, sized by the host
+    // when it fits (QT_LAUNCH_LARGE_X)
+    if (pv.extra > 0 && counts) cache = reinterpret_cast<uint32_t*>(smem + pv.extra);
+    c.cnt = cache;
     if (counts)
-      for (int m = c.t; m < c.M; m += NT) part += (double)counts[m];
-    c.tot = bsum(c, part);  // (barriers inside also publish the tables)
+      for (int m = c.t; m < c.M; m += NT) {
+        const int64_t v = counts[m];
+        part += (double)v;
+        if (cache) {  // one coalesced pass: the natural-order count lands at its R-order slot
+          cache[c.pr.rinv[m]] = (uint32_t)v;
+          wide |= (v >> 32) != 0;
+        }
+      }
+    c.tot = bsum(c, part);  // (barriers inside also publish the tables and the count cache)
     // shots check (state.py:138-141, 194-197): thread s sums the K outcomes of setting s (L2 hits: just read)
     double bad = 0.0;
     if (counts && pv.Ns) {
@@ -167,9 +182,12 @@ struct Large {
       }
     }
     c.shots_ok = !(counts && pv.Ns) || !(bmax(c, bad) > 0.0);
+    if (cache && bmax(c, wide ? 1.0 : 0.0) > 0.0) c.shots_ok = false;  // a count beyond 32 bits: not this POVM's data
   }
   // frequency of R-order row o (state.py:193, :227)
-  __device__ __forceinline__ static double freq(const Ctx& c, int o) { return (double)c.counts[c.pr.rmap[o]] / c.tot; }
+  __device__ __forceinline__ static double freq(const Ctx& c, int o) {
+    return (c.cnt ? (double)c.cnt[o] : (double)c.counts[c.pr.rmap[o]]) / c.tot;
+  }
 
   __device__ __forceinline__ static int pauli_index(int x, int z) {
     int k = 0;
@@ -368,7 +386,6 @@ struct Large {
   // cores (qt_signclip_wg.h; three d x d images: the Y overlay, the L region -- which holds nothing live here, the
   // factorisation that called us has failed -- and the X overlay).  kJacobiClip selects the cyclic Jacobi
   // eigensolver of qt_jacobi_wg.h instead (the version before round 2; kept for cross-checks).
-  static constexpr bool kJacobiClip = false;
   __device__ static cd psd_project(const Ctx& c, cd a, double eps) {
     if constexpr (kJacobiClip) {
       using J = JacobiWG<d, NT, true>;
@@ -384,6 +401,10 @@ struct Large {
   }
 
   // ---- a8: Cholesky (image in the A overlay, factor in L) ------------------------------------------
+  // Two columns per step: every thread rebuilds, from the 2 x 2 pivot block and the two pivot columns of the CURRENT
+  // image, the entries l_ik, l_i,k+1, l_jk, l_j,k+1 it needs (the column-k update of column k + 1 is applied on the
+  // fly: the same arithmetic as two one-column steps) and applies the rank-two update -- d / 2 barriers instead of d.
+  // A step costs ~900 clocks of which the barrier and the LDS round trip are most: 29 k -> see DESIGN.md section 4.5.
   __device__ static double cholesky_param(const Ctx& c, cd a, int& ok) {
     cd* A = c.Aimg();
     cd* L = c.L();
@@ -392,20 +413,33 @@ struct Large {
     L[c.e] = cd{0.0, 0.0};
     ok = 1;
     __syncthreads();
-    for (int k = 0; k < d; ++k) {
-      const double akk = A[k * LD + k].re;
-      if (!(akk > 0.0)) {  // not positive definite: nobody reads the rest of the factor (uniform: every thread sees a_kk)
+    for (int k = 0; k < d; k += 2) {
+      const double a00 = A[k * LD + k].re;
+      const cd a10 = A[(k + 1) * LD + k];
+      const double a11 = A[(k + 1) * LD + k + 1].re;
+      if (!(a00 > 0.0)) {  // not positive definite: nobody reads the rest of the factor (uniform: every thread sees the pivots)
         ok = 0;
         break;
       }
-      const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
-      const cd aik = A[i * LD + k], ajk = A[j * LD + k];
-      const cd lik{aik.re * rs, aik.im * rs}, ljk{ajk.re * rs, ajk.im * rs};
-      if (j == k && i >= k) L[c.e] = (i == k) ? cd{akk * rs, 0.0} : lik;
-      if (i > k && j > k) {
-        const cd p = cmulc(lik, ljk);
-        a.re -= p.re;
-        a.im -= p.im;
+      const double rs0 = fast_rsqrt(a00 > 1e-300 ? a00 : 1e-300);
+      const cd l10{a10.re * rs0, a10.im * rs0};
+      const double c11 = a11 - cmulc(l10, l10).re;  // pivot of column k + 1 after the column-k update
+      if (!(c11 > 0.0)) {
+        if (j == k && i >= k) L[c.e] = (i == k) ? cd{a00 * rs0, 0.0} : cscale(A[i * LD + k], rs0);
+        ok = 0;
+        break;
+      }
+      const double rs1 = fast_rsqrt(c11 > 1e-300 ? c11 : 1e-300);
+      const cd ai0 = A[i * LD + k], ai1 = A[i * LD + k + 1], aj0 = A[j * LD + k], aj1 = A[j * LD + k + 1];
+      const cd li0{ai0.re * rs0, ai0.im * rs0}, lj0{aj0.re * rs0, aj0.im * rs0};
+      const cd pi = cmulc(li0, l10), pj = cmulc(lj0, l10);
+      const cd li1{(ai1.re - pi.re) * rs1, (ai1.im - pi.im) * rs1}, lj1{(aj1.re - pj.re) * rs1, (aj1.im - pj.im) * rs1};
+      if (j == k && i >= k) L[c.e] = (i == k) ? cd{a00 * rs0, 0.0} : li0;
+      if (j == k + 1 && i >= k + 1) L[c.e] = (i == k + 1) ? cd{c11 * rs1, 0.0} : li1;
+      if (i > k + 1 && j > k + 1) {
+        const cd p0 = cmulc(li0, lj0), p1 = cmulc(li1, lj1);
+        a.re = (a.re - p0.re) - p1.re;
+        a.im = (a.im - p0.im) - p1.im;
         A[c.e] = a;
       }
       __syncthreads();
@@ -534,14 +568,11 @@ struct Large {
     g.im /= tr;
     A[c.e] = g;
     __syncthreads();
-    const cd* L = c.L();
-    cd q{0.0, 0.0};
-#pragma unroll 8
-    for (int k = 0; k < d; ++k) {  // all k (L[k][pj] = 0 for k < pj): a fixed trip count can be pipelined
-      const cd u = A[c.pi * LD + k], v = L[k * LD + c.pj];
-      q.re = fma(u.re, v.re, fma(-u.im, v.im, q.re));
-      q.im = fma(u.re, v.im, fma(u.im, v.re, q.im));
-    }
+    // Q = Gt L on the FP64 matrix cores (the product helper of the sign-function clip; result in the X overlay, which
+    // is free here): as a 2 d-read loop per thread it was LDS-bound, 14 k of the 78 k clocks of an evaluation at n = 5
+    cd* Q = c.Vimg();
+    SignClipWG<d, NT>::matmul(A, c.L(), Q);
+    const cd q = Q[c.pi * LD + c.pj];
     gt = 2.0 * (c.pkind == 2 ? q.im : q.re);
     __syncthreads();
     QT_STAMP(18);

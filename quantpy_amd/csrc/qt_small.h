@@ -263,6 +263,7 @@ struct ProductView {
   const double* P1T;    // [R1][4]  P1T[r][k] = pinv(T)[k][r]  (used when the shot weights are uniform)
   const double* wrowR;  // [M]  N_s / sum(N) of each row, R-order
   const int* rmap;      // [M]  R-order index -> row m of the (S, K) layout
+  const int* rinv;      // [M]  the inverse map: row m of the (S, K) layout -> R-order index
   const int* fwd;       // stage tables of the forward pass, stage 1 .. n concatenated: base | sel << 16
   const int* bwd;       // stage tables of the backward pass, stage n .. 1 concatenated
   int R1;

@@ -78,7 +78,7 @@ struct qt_handle {
   DevBuf kron_dig;
   int kron_S1 = 0, kron_K1 = 0;
   // product-POVM (Kronecker) description, valid when prod.enabled
-  DevBuf pr_T, pr_P1, pr_P1T, pr_wrow, pr_rmap, pr_fwd, pr_bwd, pr_aug;
+  DevBuf pr_T, pr_P1, pr_P1T, pr_wrow, pr_rmap, pr_rinv, pr_fwd, pr_bwd, pr_aug;
   qt::ProductView prod{};
   // staging for host-pointer calls
   DevBuf in0, in1, out0, out1, out2, out3, out4, proc_aug;
@@ -96,6 +96,7 @@ struct qt_handle {
   bool check_shots = true;  // qt_set_option(QT_OPT_SHOTS_CHECK) / QTOMO_SKIP_SHOTS_CHECK=1 at qt_create
   int fused_max_waves = 1024;  // qt_set_option(QT_OPT_MLE_FUSED_MAX_WAVES): largest batch (in trial-waves) of k_mle_fused
   int lds_extra = 0;  // per-trial extra LDS doubles of the launch being prepared (k_mle_bfgs); 0 otherwise
+  double ns_max = 0.0;  // largest registered shot number (product POVMs): the n >= 4 count cache holds 32-bit counts
   qt::PovmView view() const {
     return qt::PovmView{Aw.as<double>(), AwT.as<double>(), PinvT.as<double>(), M, prod, jtol2,
                         check_shots ? Ns.as<double>() : nullptr, S, K, ns_tot, lds_extra};
@@ -239,18 +240,29 @@ int prepare_large(qt_handle_t* h, bool needs_lin) {
   return 0;
 }
 #define QT_LAUNCH_LARGE(KERNEL, B_, M_, R1_, ARGS) QT_LAUNCH_LARGE_X(KERNEL, B_, M_, R1_, 0, ARGS)
+// h->lds_extra (-> PovmView::extra) = offset in doubles, while ARGS (h->view()) is evaluated, of a block at the end of
+// the LDS allocation that holds a 32-bit copy of the trial's counts in R-order (Large::make_ctx): taken whenever it fits next to everything else and the registered
+// shots fit 32 bits.
 #define QT_LAUNCH_LARGE_X(KERNEL, B_, M_, R1_, XTRA_, ARGS)                                                 \
   do {                                                                                                      \
     if (h->nq == 4) {                                                                                       \
-      const size_t lds_ = qt::Large<4>::lds_bytes(M_, R1_, XTRA_);                                          \
+      size_t lds_ = qt::Large<4>::lds_bytes(M_, R1_, XTRA_);                                                \
       if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for LDS (%zu B)", lds_);         \
+      const bool cache_ = h->prod.enabled && h->ns_max < 4294967296.0 && lds_ + 4 * (size_t)(M_) + 8 <= kLdsLimit; \
+      if (cache_) lds_ += 4 * (size_t)(M_) + 8;                                                             \
+      h->lds_extra = cache_ ? (int)((lds_ - 4 * (size_t)(M_) - 8) / 8) : 0;                                 \
       if (int r_ = allow_big_lds(KERNEL<4>, lds_)) return r_;                                               \
       hipLaunchKernelGGL((KERNEL<4>), dim3(B_), dim3(qt::Large<4>::NT), lds_, h->stream, QT_UNPACK ARGS);   \
+      h->lds_extra = 0;                                                                                     \
     } else {                                                                                                \
-      const size_t lds_ = qt::Large<5>::lds_bytes(M_, R1_, XTRA_);                                          \
+      size_t lds_ = qt::Large<5>::lds_bytes(M_, R1_, XTRA_);                                                \
       if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for LDS (%zu B)", lds_);         \
+      const bool cache_ = h->prod.enabled && h->ns_max < 4294967296.0 && lds_ + 4 * (size_t)(M_) + 8 <= kLdsLimit; \
+      if (cache_) lds_ += 4 * (size_t)(M_) + 8;                                                             \
+      h->lds_extra = cache_ ? (int)((lds_ - 4 * (size_t)(M_) - 8) / 8) : 0;                                 \
       if (int r_ = allow_big_lds(KERNEL<5>, lds_)) return r_;                                               \
       hipLaunchKernelGGL((KERNEL<5>), dim3(B_), dim3(qt::Large<5>::NT), lds_, h->stream, QT_UNPACK ARGS);   \
+      h->lds_extra = 0;                                                                                     \
     }                                                                                                       \
   } while (0)
 
@@ -336,7 +348,8 @@ void qt_destroy(qt_handle_t* h) {
   if (!h) return;
   DeviceScope scope(h->device);
   (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->pr_T, &h->pr_P1, &h->pr_P1T, &h->pr_wrow, &h->pr_rmap, &h->pr_fwd, &h->pr_bwd, &h->pr_aug}) b->release();
+  for (DevBuf* b : {&h->pr_T, &h->pr_P1, &h->pr_P1T, &h->pr_wrow, &h->pr_rmap, &h->pr_rinv, &h->pr_fwd, &h->pr_bwd, &h->pr_aug})
+    b->release();
   for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->kron_dig, &h->in0, &h->in1,
                     &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug, &h->ws_x, &h->ws_g, &h->ws_f,
                     &h->ws_act, &h->hess, &h->sort_alt, &h->sort_tmp})
@@ -644,6 +657,10 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
       bwd.push_back((int)((rpre * R1 * Kq + krest) | (kq << 16)));
     }
   }
+  std::vector<int> rinv((size_t)M);
+  for (long long mr = 0; mr < M; ++mr) rinv[(size_t)rmap[mr]] = (int)mr;
+  HIPCHK(h->pr_rinv.ensure(rinv.size() * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(h->pr_rinv.p, rinv.data(), rinv.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h->pr_rmap.ensure(rmap.size() * sizeof(int)));
   HIPCHK(h->pr_wrow.ensure(wrow.size() * sizeof(double)));
   HIPCHK(h->pr_fwd.ensure(fwd.size() * sizeof(int)));
@@ -661,6 +678,9 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
   h->prod.P1T = h->pr_P1T.as<double>();
   h->prod.wrowR = h->pr_wrow.as<double>();
   h->prod.rmap = h->pr_rmap.as<int>();
+  h->prod.rinv = h->pr_rinv.as<int>();
+  h->ns_max = 0.0;
+  for (double v : ns) h->ns_max = v > h->ns_max ? v : h->ns_max;
   h->prod.fwd = h->pr_fwd.as<int>();
   h->prod.bwd = h->pr_bwd.as<int>();
   h->prod.R1 = R1;

@@ -162,15 +162,31 @@ struct Large {
     // when it fits (QT_LAUNCH_LARGE_X)
     if (pv.extra > 0 && counts) cache = reinterpret_cast<uint32_t*>(smem + pv.extra);
     c.cnt = cache;
-    if (counts)
-      for (int m = c.t; m < c.M; m += NT) {
-        const int64_t v = counts[m];
-        part += (double)v;
-        if (cache) {  // one coalesced pass: the natural-order count lands at its R-order slot
-          cache[c.pr.rinv[m]] = (uint32_t)v;
-          wide |= (v >> 32) != 0;
+    if (counts) {
+      // eight rows per thread and pass, every load of a pass requested before the first is used (as a plain loop each
+      // iteration waited out its own HBM round trip: the counts are the only cold read of a trial, 62 KB at n = 5)
+      for (int m0 = c.t; m0 < c.M; m0 += 8 * NT) {
+        int64_t v[8];
+        int ri[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int m = m0 + u * NT;
+          const int mm = m < c.M ? m : c.M - 1;
+          v[u] = counts[mm];
+          ri[u] = cache ? c.pr.rinv[mm] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (m0 + u * NT < c.M) {
+            part += (double)v[u];
+            if (cache) {  // the natural-order count lands at its R-order slot
+              cache[ri[u]] = (uint32_t)v[u];
+              wide |= (v[u] >> 32) != 0;
+            }
+          }
         }
       }
+    }
     c.tot = bsum(c, part);  // (barriers inside also publish the tables and the count cache)
     // shots check (state.py:138-141, 194-197): thread s sums the K outcomes of setting s (L2 hits: just read)
     double bad = 0.0;
@@ -401,10 +417,11 @@ struct Large {
   }
 
   // ---- a8: Cholesky (image in the A overlay, factor in L) ------------------------------------------
-  // Two columns per step: every thread rebuilds, from the 2 x 2 pivot block and the two pivot columns of the CURRENT
-  // image, the entries l_ik, l_i,k+1, l_jk, l_j,k+1 it needs (the column-k update of column k + 1 is applied on the
-  // fly: the same arithmetic as two one-column steps) and applies the rank-two update -- d / 2 barriers instead of d.
-  // A step costs ~900 clocks of which the barrier and the LDS round trip are most: 29 k -> see DESIGN.md section 4.5.
+  // One column per step and barrier.  Measured alternatives at n = 5 / n = 4 (profiles/round2_*large*): two columns per
+  // step (half the barriers, every thread rebuilding both pivot columns) 27.4 k vs 28.7 k clocks at n = 5 but 20 %
+  // SLOWER end to end at n = 4 -- a step is a chain of dependent latencies (LDS round trip, 1/sqrt, LDS write,
+  // barrier), not issue- or barrier-bound, so neither halving the barriers nor idling the wavefronts above the pivot
+  // row changes it.  Kept: the uniform early exit at the first non-positive pivot.
   __device__ static double cholesky_param(const Ctx& c, cd a, int& ok) {
     cd* A = c.Aimg();
     cd* L = c.L();
@@ -413,33 +430,20 @@ struct Large {
     L[c.e] = cd{0.0, 0.0};
     ok = 1;
     __syncthreads();
-    for (int k = 0; k < d; k += 2) {
-      const double a00 = A[k * LD + k].re;
-      const cd a10 = A[(k + 1) * LD + k];
-      const double a11 = A[(k + 1) * LD + k + 1].re;
-      if (!(a00 > 0.0)) {  // not positive definite: nobody reads the rest of the factor (uniform: every thread sees the pivots)
+    for (int k = 0; k < d; ++k) {
+      const double akk = A[k * LD + k].re;
+      if (!(akk > 0.0)) {  // not positive definite: nobody reads the rest of the factor (uniform: every thread sees a_kk)
         ok = 0;
         break;
       }
-      const double rs0 = fast_rsqrt(a00 > 1e-300 ? a00 : 1e-300);
-      const cd l10{a10.re * rs0, a10.im * rs0};
-      const double c11 = a11 - cmulc(l10, l10).re;  // pivot of column k + 1 after the column-k update
-      if (!(c11 > 0.0)) {
-        if (j == k && i >= k) L[c.e] = (i == k) ? cd{a00 * rs0, 0.0} : cscale(A[i * LD + k], rs0);
-        ok = 0;
-        break;
-      }
-      const double rs1 = fast_rsqrt(c11 > 1e-300 ? c11 : 1e-300);
-      const cd ai0 = A[i * LD + k], ai1 = A[i * LD + k + 1], aj0 = A[j * LD + k], aj1 = A[j * LD + k + 1];
-      const cd li0{ai0.re * rs0, ai0.im * rs0}, lj0{aj0.re * rs0, aj0.im * rs0};
-      const cd pi = cmulc(li0, l10), pj = cmulc(lj0, l10);
-      const cd li1{(ai1.re - pi.re) * rs1, (ai1.im - pi.im) * rs1}, lj1{(aj1.re - pj.re) * rs1, (aj1.im - pj.im) * rs1};
-      if (j == k && i >= k) L[c.e] = (i == k) ? cd{a00 * rs0, 0.0} : li0;
-      if (j == k + 1 && i >= k + 1) L[c.e] = (i == k + 1) ? cd{c11 * rs1, 0.0} : li1;
-      if (i > k + 1 && j > k + 1) {
-        const cd p0 = cmulc(li0, lj0), p1 = cmulc(li1, lj1);
-        a.re = (a.re - p0.re) - p1.re;
-        a.im = (a.im - p0.im) - p1.im;
+      const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
+      const cd aik = A[i * LD + k], ajk = A[j * LD + k];
+      const cd lik{aik.re * rs, aik.im * rs}, ljk{ajk.re * rs, ajk.im * rs};
+      if (j == k && i >= k) L[c.e] = (i == k) ? cd{akk * rs, 0.0} : lik;
+      if (i > k && j > k) {
+        const cd p = cmulc(lik, ljk);
+        a.re -= p.re;
+        a.im -= p.im;
         A[c.e] = a;
       }
       __syncthreads();

@@ -378,14 +378,23 @@ def main():
         pure = qp.Qobj(np.outer(psi, psi.conj()))
         np.random.seed(9)
         pure_counts = np.stack([simulate_counts(povm, pure.bloch, shots) for _ in range(B)])
-        for name, cts, init in (("configs[1] counts, init='mixed'", counts, "mixed"),
-                                ("rank-1 state, 1e5 shots, init='lin'", pure_counts, "lin")):
+        # (The 1000-trial figure of the 'lin'-start case is not taken in the default run: its launches would carry the
+        #  name of the timed kernel, k_mle_fused<3,false>, and skew a profiler's per-kernel average of the headline step;
+        #  the fully mixed start runs as k_mle_fused_mixed.  scripts/iterating_timing.py measures both.)
+        for name, cts, init, small in (("configs[1] counts, init='mixed'", counts, "mixed", True),
+                                       ("rank-1 state, 1e5 shots, init='lin'", pure_counts, "lin", False)):
             c_d = torch.from_numpy(np.ascontiguousarray(cts)).cuda()
-            r_d = torch.empty((len(cts), d, d), dtype=torch.complex128, device="cuda")
-            ni_d = torch.zeros(len(cts), dtype=torch.int32, device="cuda")
-            nf_d = torch.zeros(len(cts), dtype=torch.int32, device="cuda")
-            s_d = torch.zeros(len(cts), dtype=torch.int32, device="cuda")
-            ms = timed(lambda: eng.mle_dev(c_d, r_d, init=init, nit=ni_d, nfev=nf_d, status=s_d), 20)
+            nb = len(cts) if small else 64
+            r_d = torch.empty((nb, d, d), dtype=torch.complex128, device="cuda")
+            ni_d = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            nf_d = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            s_d = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            run_small = lambda: eng.mle_dev(c_d[:nb], r_d, init=init, nit=ni_d, nfev=nf_d, status=s_d)  # noqa: E731
+            if small:
+                ms = timed(run_small, 20)
+            else:
+                run_small()
+                eng.sync()
             r_h, ni_h = r_d.cpu().numpy(), ni_d.cpu().numpy()
             same_nit, worst = 0, 0.0
             for i in range(64):
@@ -395,13 +404,15 @@ def main():
             Bs = 65536
             big = c_d.repeat((Bs + len(cts) - 1) // len(cts), 1, 1)[:Bs].contiguous()
             rb = torch.empty((Bs, d, d), dtype=torch.complex128, device="cuda")
-            ms_big = timed(lambda: eng.mle_dev(big, rb, init=init), 3)
-            iterating[name] = {
-                "batch": len(cts), "ms_per_step": round(ms, 4), "value": round(len(cts) / ms * 1e3, 1),
-                "unit": "reconstructions/s", "mean_nit": float(ni_h.mean()), "max_nit": int(ni_h.max()),
-                "mean_nfev": float(nf_d.float().mean().item()), "nonzero_status": int((s_d != 0).sum().item()),
-                "parity_vs_oracle_64_trials": {"identical_nit": same_nit, "max_infidelity": float(f"{worst:.3e}")},
-                "saturated": {"batch": Bs, "ms_per_step": round(ms_big, 3), "value": round(Bs / ms_big * 1e3, 1)}}
+            nib = torch.zeros(Bs, dtype=torch.int32, device="cuda")
+            ms_big = timed(lambda: eng.mle_dev(big, rb, init=init, nit=nib), 3)
+            entry = {"unit": "reconstructions/s", "mean_nit": float(nib.float().mean().item()), "max_nit": int(nib.max().item()),
+                     "nonzero_status": int((s_d != 0).sum().item()),
+                     "parity_vs_oracle_64_trials": {"identical_nit": same_nit, "max_infidelity": float(f"{worst:.3e}")},
+                     "saturated": {"batch": Bs, "ms_per_step": round(ms_big, 3), "value": round(Bs / ms_big * 1e3, 1)}}
+            if small:
+                entry.update(batch=nb, ms_per_step=round(ms, 4), value=round(nb / ms * 1e3, 1))
+            iterating[name] = entry
             del big, rb
 
     # ---- the other single-GPU configurations of BASELINE.json, one short measurement each ---------

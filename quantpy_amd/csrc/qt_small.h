@@ -1648,11 +1648,11 @@ constexpr int kFusedLdsPairs = 24;  // (s, y) pairs of k_mle_fused<3> kept in LD
 // handicap: start point, first evaluation and -- for the waves that still hold an open trial -- the BFGS
 // loop.  Saves the second launch (2.5-4 us when nothing iterates, ~10 % of a 1000-trial step).
 template <int NQ, bool ALDS>
-__global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* __restrict__ counts, int B, int init,
-                                                   int max_iter, double gtol, double* __restrict__ rho,
-                                                   int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
-                                                   double* __restrict__ fun_out, int32_t* __restrict__ status_out,
-                                                   double* __restrict__ pairs) {
+__device__ __forceinline__ void mle_fused_body(const PovmView& pv, const int64_t* __restrict__ counts, int B, int init,
+                                               int max_iter, double gtol, double* __restrict__ rho,
+                                               int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
+                                               double* __restrict__ fun_out, int32_t* __restrict__ status_out,
+                                               double* __restrict__ pairs) {
   using S = Small<NQ, ALDS>;
   constexpr int D = S::D, G = S::G, d = S::d;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1724,6 +1724,25 @@ __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* _
                                               status_out, pairs);
   else
     bfgs_iterate<NQ, ALDS>(c, iterate, xk, gk, fk, b, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out);
+}
+
+// Two entry points over the same body: the fully mixed start (`init = 'mixed'`: every trial iterates, ~10x the duration)
+// runs under its own kernel name, so that a profiler's per-kernel average of k_mle_fused is the average of the
+// 'lin'-start launches (bench.py's timed steps) and not a mixture with the iterating side measurements.
+template <int NQ, bool ALDS>
+__global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* __restrict__ counts, int B, int max_iter,
+                                                   double gtol, double* __restrict__ rho, int32_t* __restrict__ nit_out,
+                                                   int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,
+                                                   int32_t* __restrict__ status_out, double* __restrict__ pairs) {
+  mle_fused_body<NQ, ALDS>(pv, counts, B, 0, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out, pairs);
+}
+template <int NQ, bool ALDS>
+__global__ void __launch_bounds__(256) k_mle_fused_mixed(PovmView pv, const int64_t* __restrict__ counts, int B,
+                                                         int max_iter, double gtol, double* __restrict__ rho,
+                                                         int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
+                                                         double* __restrict__ fun_out, int32_t* __restrict__ status_out,
+                                                         double* __restrict__ pairs) {
+  mle_fused_body<NQ, ALDS>(pv, counts, B, 1, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out, pairs);
 }
 
 // Metropolis-Hastings chain on the Cholesky parameters (reference mhmc.py:80-119 with

@@ -964,8 +964,13 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
         const int over = mi > qt::kFusedLdsPairs ? mi : 1;  // (indexed by pair number: rows below kFusedLdsPairs stay unused)
         HIPCHK(h->hess.ensure((size_t)B * over * 2 * h->D * sizeof(double)));
       }
-      QT_LAUNCH_SMALL(qt::k_mle_fused, h->M, B,
-                      (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, h->hess.as<double>()));
+      if (init == QT_INIT_LIN) {
+        QT_LAUNCH_SMALL(qt::k_mle_fused, h->M, B,
+                        (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, h->hess.as<double>()));
+      } else {
+        QT_LAUNCH_SMALL(qt::k_mle_fused_mixed, h->M, B,
+                        (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, h->hess.as<double>()));
+      }
       h->lds_extra = 0;
     } else {
       HIPCHK(h->ws_x.ensure(nel * sizeof(double)));

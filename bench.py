@@ -256,19 +256,19 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.sync()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()  # (the engine runs on torch's current stream: this covers its work)
     barrier()
-    torch.cuda.synchronize()
+    if use_dist:
+        torch.cuda.synchronize()  # an RCCL barrier is itself GPU work
     t0 = time.perf_counter()
     eng.timer_begin()
     for _ in range(args.steps):
         step()
-    kernel_ms = eng.timer_end() / args.steps  # HIP events on the stream the kernel runs on
-    eng.sync()
+    kernel_ms = eng.timer_end() / args.steps  # HIP events on the stream the kernel runs on (waits for the last step)
     torch.cuda.synchronize()
     barrier()
-    torch.cuda.synchronize()
+    if use_dist:
+        torch.cuda.synchronize()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     assert torch.cuda.current_device() == dev_index  # engine calls leave the thread's device alone
 
@@ -338,6 +338,12 @@ def main():
                "hbm_GBps": round(bytes_per_recon * Bs / (ms * 1e-3) / 1e9, 2),
                "fp64_TFLOPs_dense_equivalent": round(flops_trial * Bs / (ms * 1e-3) / 1e12, 3)}
         del big, rho_s
+        if isinstance(executed, dict) and "valu_per_reconstruction" in executed and Bs == 65536:
+            # executed VALU wave-instructions (PMC, committed under profiles/) against the chip's measured issue rate
+            ceil_ns = executed.get("valu_issue_ceiling_ns_per_wave_instruction_per_simd", 2.57)
+            busy_ms = executed["valu_per_reconstruction"] * Bs / 1024 * ceil_ns * 1e-6
+            executed = dict(executed, valu_issue_utilisation_at_B65536=round(busy_ms / ms, 4), mfma_utilisation=0.0)
+            roofline["executed_instruction_utilisation"] = executed
 
     # ---- the same steps issued alternately on two handles (two HIP streams) ----------------------
     piped = None

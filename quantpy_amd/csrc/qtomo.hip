@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -67,7 +68,7 @@ struct qt_handle {
   int device = 0, nq = 0, d = 0, D = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
   // POVM cache.  The dense operands A, A^T, A', A'^T ([M][D] each: 64 MB at n = 5) exist when `dense_ready`;
   // a product POVM at n >= 4 never reads them and builds them only on demand (ensure_dense), likewise the dense
   // left inverse (`pinv_ready`, compute_dense_pinv).
@@ -169,9 +170,27 @@ int fetch_out(qt_handle_t* h, const T* dev, T* dst, size_t count, int flags) {
   HIPCHK(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
   return 0;
 }
+// Wait for the handle's stream.  hipStreamSynchronize / hipEventSynchronize park the thread and wake it through an
+// interrupt: ~50 us of latency measured around a 330 us timed region (20 steps of bench.py) and on every host-pointer
+// call.  Most waits here are shorter than a millisecond, so: record an event, poll it for up to ~2 ms, then block.
+int wait_event_spin(hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return fail(QT_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+  }
+  HIPCHK(hipEventSynchronize(ev));
+  return 0;
+}
+int wait_stream(qt_handle_t* h) {
+  HIPCHK(hipEventRecord(h->ev_sync, h->stream));
+  return wait_event_spin(h->ev_sync);
+}
 int finish(qt_handle_t* h, int flags) {
   HIPCHK(hipGetLastError());
-  if (!(flags & QT_DEVICE_PTR)) HIPCHK(hipStreamSynchronize(h->stream));
+  if (!(flags & QT_DEVICE_PTR)) return wait_stream(h);
   return 0;
 }
 int count_bad(const int32_t* status, int B, int flags) {
@@ -334,7 +353,8 @@ qt_handle_t* qt_create(int device, int n_qubits) {
   h->d = 1 << n_qubits;
   h->D = h->d * h->d;
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&h->ev_sync, hipEventDisableTiming)) != hipSuccess) {
     fail(QT_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e));
     delete h;
     return nullptr;
@@ -357,14 +377,14 @@ void qt_destroy(qt_handle_t* h) {
   h->proc.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
 int qt_sync(qt_handle_t* h) {
   QT_ENTER(h);
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
+  return wait_stream(h);
 }
 
 int qt_set_stream(qt_handle_t* h, void* hip_stream) {
@@ -403,7 +423,7 @@ int qt_timer_end(qt_handle_t* h, double* elapsed_ms) {
   QT_ENTER(h);
   if (!elapsed_ms) return fail(QT_ERR_ARG, "null elapsed_ms");
   HIPCHK(hipEventRecord(h->ev1, h->stream));
-  HIPCHK(hipEventSynchronize(h->ev1));
+  if (int r = wait_event_spin(h->ev1)) return r;
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *elapsed_ms = ms;

@@ -280,3 +280,41 @@ def test_true_mub_povm_as_custom_array_n3(oracle):
     mle = t.point_estimate("mle")
     ref, ri = oracle.mle_estimate(t.results, povm, return_info=True, solver="port")
     assert t.mle_info["nit"] == ri["nit"] and ri["nit"] > 0 and abs(oracle.infidelity(ref, mle.matrix)) < 1e-6
+
+
+def test_options_and_iteration_limits(oracle):
+    """qt_set_option argument checks; max_iter limits of the n = 3 BFGS kernels (LDS holds the two-loop scalars):
+    <= 256 iterations in one launch, <= 2000 through the split pair, beyond that a clear error -- and a long run
+    (max_iter = 300, tol = 0: every trial iterates until the line search gives up or the cap) agrees between the forms."""
+    import quantpy_amd as qp
+    from quantpy_amd import _capi
+
+    eng = qp.Engine(3)
+    with pytest.raises(qp.EngineError):
+        eng.set_option(99, 1)
+    with pytest.raises(qp.EngineError):
+        eng.set_option(_capi.QT_OPT_MLE_FUSED_MAX_WAVES, -1)
+    a = qp.generate_measurement_matrix("proj-set", 3)
+    rng = np.random.default_rng(4)
+    g = rng.standard_normal((8, 1)) + 1j * rng.standard_normal((8, 1))
+    rho = g @ g.conj().T
+    rho /= np.trace(rho)
+    np.random.seed(8)
+    counts = np.stack([oracle.sample_counts(np.asarray(a), oracle.bloch_from_matrix(rho), 200) for _ in range(3)])
+    eng.set_povm(a, counts[0].sum(-1))
+    with pytest.raises(qp.EngineError) as ei:
+        eng.mle(counts, max_iter=2001)
+    assert ei.value.code == _capi.QT_ERR_UNSUPPORTED
+    r_fused, i_fused = eng.mle(counts, max_iter=40, tol=1e-6, return_info=True)  # > 24 pairs: LDS pairs + global pairs
+    eng.set_option(_capi.QT_OPT_MLE_FUSED_MAX_WAVES, 0)
+    r_split, i_split = eng.mle(counts, max_iter=40, tol=1e-6, return_info=True)
+    r_long, i_long = eng.mle(counts, max_iter=300, tol=1e-6, return_info=True)  # > 256: always the split pair
+    eng.set_option(_capi.QT_OPT_MLE_FUSED_MAX_WAVES, 1024)
+    assert np.array_equal(i_fused["nit"], i_split["nit"]) and np.array_equal(i_fused["status"], i_split["status"])
+    assert np.abs(r_fused - r_split).max() < 1e-12
+    for c, r, nit, st in zip(counts, r_fused, i_fused["nit"], i_fused["status"]):
+        ref, ri = oracle.mle_estimate(c, np.asarray(a), max_iter=40, tol=1e-6, return_info=True, solver="port")
+        assert nit == ri["nit"] and abs(oracle.infidelity(ref, r)) < 1e-6
+        assert nit > 24 or st != 3  # the case is meant to go past the LDS-resident pairs
+    assert np.all(i_long["nit"] >= i_fused["nit"])
+    eng.close()

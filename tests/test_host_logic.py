@@ -194,6 +194,9 @@ want = np.arange(n * 3).reshape(n, 3).sum(axis=1) * 0.5
 lo, hi = qd.shard_bounds(n)
 assert out.shape == (n,) and np.array_equal(out, want), (rank, out, want)
 assert sum(seen) == hi - lo
+import torch
+full = qd.allgather_device(torch.from_numpy(want[lo:hi].copy()), n)   # the tensor form bench.py uses (gloo: host path)
+assert full.shape == (n,) and np.array_equal(full.numpy(), want), (rank, full)
 print(f"rank {rank}/{ws} ok {hi - lo}", flush=True)
 dist.destroy_process_group()
 '''

@@ -684,25 +684,32 @@ __global__ void __launch_bounds__(256) k_lifp_freq(const int64_t* __restrict__ c
 // as in k_born_mfma (qt_ops.h): lane (r16, kq) supplies A[r16][kq] and B[kq][r16], and receives rows
 // kq + 4 r of column r16.  Column n = 2 v + part of the product is the re / im part of Choi-vector entry
 // v = col * DC + row (routines.py:59-61), i.e. of element (row, col): written straight to choi[b][row][col].
-template <int DC>
+// NC = 16-column tiles per workgroup.  NC = 2 (round 2): a wavefront feeds each A fragment (16 processes x 4 k-values,
+// streamed from global memory) into TWO column tiles, so the frequency matrix F is re-read by 16 instead of 32 column
+// slices (at B = 1024 the 32 slices pulled 151 MB of F through L2 for a 0.6 GFLOP product -- the kernel was bound by
+// that, not by the matrix cores) and every wavefront carries two independent MFMA chains.  LDS: [Rp][16 NC] doubles
+// (147 KB at R = 576, NC = 2: one workgroup per CU, 16 x 16 = 256 workgroups at B = 1024) + the split-K scratch.
+template <int DC, int NC>
 __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F, int B, int R, int Rp,
                                                    const double* __restrict__ pinvT, double* __restrict__ choi,
                                                    int32_t* __restrict__ status, int32_t* __restrict__ zero_iters) {
-  constexpr int NE = DC * DC, N = 2 * NE;
-  extern __shared__ double s_p[];  // [Rp][16] (rows R .. Rp-1 zero), then 4 x 256 doubles for the split-K sum
-  const int c0 = blockIdx.x * 16;
-  // (twelve loads in flight per thread: written as a plain copy loop, each iteration waits out an L2 round trip)
-  for (int e0 = threadIdx.x; e0 < Rp * 16; e0 += 12 * 512) {
-    double t[12];
+  constexpr int NE = DC * DC, N = 2 * NE, W = 16 * NC;
+  extern __shared__ double s_p[];  // [Rp][W] (rows R .. Rp-1 zero), then 4 x NC x 256 doubles for the split-K sum
+  const int c0 = blockIdx.x * W;
+  // Staging the slice is the longest phase of the kernel (147 KB per workgroup against ~2 us of MFMA work): eighteen
+  // 16-byte loads in flight per thread -- the whole slice at R = 576 in ONE round trip to L2 (it was three rounds of
+  // twelve 8-byte loads).  W is even and c0 a multiple of W, so a pair never straddles a row.
+  for (int e0 = 2 * threadIdx.x; e0 < Rp * W; e0 += 18 * 1024) {
+    double2 t[18];
 #pragma unroll
-    for (int u = 0; u < 12; ++u) {
-      const int e = e0 + u * 512;
-      t[u] = e < R * 16 ? pinvT[(size_t)(e >> 4) * N + c0 + (e & 15)] : 0.0;
+    for (int u = 0; u < 18; ++u) {
+      const int e = e0 + u * 1024;
+      t[u] = e < R * W ? *reinterpret_cast<const double2*>(pinvT + (size_t)(e / W) * N + c0 + (e % W)) : double2{0.0, 0.0};
     }
 #pragma unroll
-    for (int u = 0; u < 12; ++u) {
-      const int e = e0 + u * 512;
-      if (e < Rp * 16) s_p[e] = t[u];
+    for (int u = 0; u < 18; ++u) {
+      const int e = e0 + u * 1024;
+      if (e < Rp * W) *reinterpret_cast<double2*>(s_p + e) = t[u];
     }
   }
   __syncthreads();
@@ -721,58 +728,79 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
   // in 16-byte pairs: the four lane groups of a row read one full 64-byte line per load (the plain
   // k0 + 4 u + kq order makes every load 16 half-used lines of 8 bytes per lane), and the swapped order inside
   // the pairs of the odd lane groups keeps the B-operand rows of lane groups {0, 1} and {2, 3} on opposite
-  // halves of the LDS banks (row pitch 128 bytes).  No bounds tests in the loop: the slice is zero-padded to
+  // halves of the LDS banks.  No bounds tests in the loop: the slice is zero-padded to
   // Rp rows and so is every row of F (pitch Rp); the look-ahead of a row's last chunk reads the start of the next
   // row (or the 192 zeros behind the last one) and is not used.  Rows beyond B compute on row 0 and are not stored.
   const double2* fr = reinterpret_cast<const double2*>(F + (size_t)(row < B ? row : 0) * Rp) + kq;
   const bool swap = kq & 1;
-  v4f64 acc = {0.0, 0.0, 0.0, 0.0};  // (a second accumulator for the odd steps was measured: no gain, 37 -> 40 us)
-  double2 a[8], an[8];
+  v4f64 acc[NC];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) a[j] = fr[(kbeg + 8 * j) / 2];
+  for (int c = 0; c < NC; ++c) acc[c] = v4f64{0.0, 0.0, 0.0, 0.0};
+  // The A operand runs TWO chunks ahead of the MFMAs (a chunk's 16 / 32 MFMAs take ~1 000 clocks, an L2 round trip
+  // of a wavefront with one neighbour on its SIMD several times that: one chunk of look-ahead left the matrix cores
+  // waiting -- 28 us for 0.6 GFLOP).  Look-aheads past the end wrap to the first chunk and are not used (no branch:
+  // a branch would let the compiler sink the loads below the MFMA chain).
+  double2 a[8], an[8], an2[8];
+  const int k1 = kbeg + 64 < kend ? kbeg + 64 : kbeg;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = fr[(kbeg + 8 * j) / 2];
+    an[j] = fr[(k1 + 8 * j) / 2];
+  }
   for (int k0 = kbeg; k0 < kend; k0 += 64) {
-    // next chunk's A operand, requested before this chunk's MFMAs (the last iteration re-reads the first chunk:
-    // a branch here would let the compiler sink the loads below the MFMA chain)
-    const int kn = k0 + 64 < kend ? k0 + 64 : kbeg;
+    const int kn = k0 + 128 < kend ? k0 + 128 : kbeg;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) an[j] = fr[(kn + 8 * j) / 2];
-    // all 16 B-operand reads of the chunk first (two base addresses, immediate offsets), then the MFMA chain
-    const double* b_first = s_p + (k0 + 2 * kq + (swap ? 1 : 0)) * 16 + r16;
-    const double* b_second = s_p + (k0 + 2 * kq + (swap ? 0 : 1)) * 16 + r16;
-    double b0[8], b1[8];
+    for (int j = 0; j < 8; ++j) an2[j] = fr[(kn + 8 * j) / 2];
+    // all B-operand reads of the chunk first (two base addresses, immediate offsets), then the MFMA chains
+    const double* b_first = s_p + (k0 + 2 * kq + (swap ? 1 : 0)) * W + r16;
+    const double* b_second = s_p + (k0 + 2 * kq + (swap ? 0 : 1)) * W + r16;
+    double b0[NC][8], b1[NC][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      b0[j] = b_first[8 * j * 16];
-      b1[j] = b_second[8 * j * 16];
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        b0[c][j] = b_first[8 * j * W + 16 * c];
+        b1[c][j] = b_second[8 * j * W + 16 * c];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const double lo = swap ? a[j].y : a[j].x, hi = swap ? a[j].x : a[j].y;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, b0[j], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, b1[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, b0[c][j], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, b1[c][j], acc[c], 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = an[j];
+    for (int j = 0; j < 8; ++j) {
+      a[j] = an[j];
+      an[j] = an2[j];
+    }
   }
-  double* red = s_p + Rp * 16 + grp * 256;
+  double* red = s_p + Rp * W + grp * 256 * NC;
   if (half) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[r * 64 + lane] = acc[r];
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(c * 4 + r) * 64 + lane] = acc[c][r];
   }
   __syncthreads();
   if (!half) {
-    const int n = c0 + r16, v = n >> 1, part = n & 1;
-    const int er = v % DC, ec = v / DC;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int orow = g * 16 + kq + 4 * r;
-      if (orow < B) {
-        const double x = acc[r] + red[r * 64 + lane];
-        choi[((size_t)orow * NE + er * DC + ec) * 2 + part] = x;
-        if (n == 0) {  // Re C[0][0], the element k_lifp_batch tests; no projection follows when these are set
-          if (status) status[orow] = (x == x) ? 0 : 4;
-          if (zero_iters) zero_iters[orow] = 0;
+    for (int c = 0; c < NC; ++c) {
+      const int n = c0 + 16 * c + r16, v = n >> 1, part = n & 1;
+      const int er = v % DC, ec = v / DC;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = g * 16 + kq + 4 * r;
+        if (orow < B) {
+          const double x = acc[c][r] + red[(c * 4 + r) * 64 + lane];
+          choi[((size_t)orow * NE + er * DC + ec) * 2 + part] = x;
+          if (n == 0) {  // Re C[0][0], the element k_lifp_batch tests; no projection follows when these are set
+            if (status) status[orow] = (x == x) ? 0 : 4;
+            if (zero_iters) zero_iters[orow] = 0;
+          }
         }
       }
     }

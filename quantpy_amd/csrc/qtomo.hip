@@ -1190,6 +1190,7 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
   if (dyn > 32 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the process kernel");
   const int R = D * M, Rp = (R + 63) / 64 * 64;
   const size_t gemm_lds = ((size_t)Rp * 16 + 4 * 256) * sizeof(double);
+  const size_t gemm_lds2 = ((size_t)Rp * 32 + 4 * 512) * sizeof(double);  // two column tiles per workgroup
   if (D == 4) {
     hipLaunchKernelGGL(qt::k_lifp_batch<4>, dim3(B), dim3(qt::ProcWG<4>::NT), dyn, h->stream, dc, B, M,
                        (const double*)h->proc.pinvT, cptp, dchoi, dit, dst);
@@ -1204,15 +1205,21 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
       raw = h->ws_g.as<double>();
     }
     hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 15) / 16), dim3(256), 0, h->stream, dc, B * D, M, D, Rp, F);
-    if (int r = allow_big_lds(qt::k_lifp_gemm<16>, gemm_lds)) return r;
     // 4 groups of 16 processes per workgroup pass (x 2 halves of K).  A workgroup keeps its operand slice for up
     // to 4 passes once there are enough blocks to fill the chip anyway (measured: B = 1024 best with 1-2 passes,
     // 26 M/s; B = 8192 with 4, 38 M/s against 35 M/s with 1)
     const int nblocks = (B + 63) / 64;
     const int passes = nblocks >= 64 ? 4 : (nblocks >= 32 ? 2 : 1);
     const int row_blocks = (nblocks + passes - 1) / passes;
-    hipLaunchKernelGGL(qt::k_lifp_gemm<16>, dim3(2 * NE / 16, row_blocks), dim3(512), gemm_lds, h->stream, F, B, R, Rp,
-                       (const double*)h->proc.pinvT, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
+    if (gemm_lds2 <= kLdsLimit) {  // two column tiles per workgroup: half the re-reads of F (R <= 576)
+      if (int r = allow_big_lds(qt::k_lifp_gemm<16, 2>, gemm_lds2)) return r;
+      hipLaunchKernelGGL((qt::k_lifp_gemm<16, 2>), dim3(2 * NE / 32, row_blocks), dim3(512), gemm_lds2, h->stream, F, B, R, Rp,
+                         (const double*)h->proc.pinvT, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
+    } else {
+      if (int r = allow_big_lds(qt::k_lifp_gemm<16, 1>, gemm_lds)) return r;
+      hipLaunchKernelGGL((qt::k_lifp_gemm<16, 1>), dim3(2 * NE / 16, row_blocks), dim3(512), gemm_lds, h->stream, F, B, R, Rp,
+                         (const double*)h->proc.pinvT, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
+    }
     if (cptp)
       hipLaunchKernelGGL(qt::k_cptp_project<16>, dim3(B), dim3(qt::ProcWG<16>::NT), 0, h->stream, (const double*)raw, B, 0,
                          1000, 1e-12, dchoi, dit, dst);

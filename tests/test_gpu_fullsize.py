@@ -84,8 +84,18 @@ def test_c5_size_properties(oracle):
     exact = np.stack([_exact_counts(oracle, pv, r, 10**13) for r in states])
     eng.set_povm(povm, np.ones(povm.shape[0]) * 1e13)
     assert np.abs(eng.lin(exact, physical=False) - states).max() < 1e-9
+    # the eigenvalue clip (sign-function iteration, qt_signclip_wg.h) on spectra with exact zeros: rank-1 and rank-2 states
+    # from exact probabilities come back as themselves (eigenvalues 0 +- 1e-16 are clipped to 1e-15, nothing else moves),
+    # and a rank-1 state from SAMPLED counts (15 / 16 of the spectrum scattered around zero) matches the eigh-based clip
+    low = np.stack([_ginibre(rng, d, rank=1), _ginibre(rng, d, rank=2)])
+    back = eng.lin(np.stack([_exact_counts(oracle, pv, r, 10**13) for r in low]), physical=True)
+    assert np.abs(back - low).max() < 1e-9 and np.linalg.eigvalsh(back).min() > -1e-14
     shots = np.ones(povm.shape[0]) * 10**6
     eng.set_povm(povm, shots)
+    np.random.seed(15)
+    noisy = simulate_counts(povm, qp.Qobj(low[0]).bloch, shots)
+    got = eng.lin(noisy, physical=True)
+    assert np.abs(got - oracle.lin_estimate(noisy, pv)).max() < 1e-10
     np.random.seed(5)
     few = np.stack([simulate_counts(povm, qp.Qobj(states[0]).bloch, shots) for _ in range(6)])
     counts = np.concatenate([few] * (B // 6))

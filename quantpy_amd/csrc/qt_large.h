@@ -574,9 +574,20 @@ struct Large {
     __syncthreads();
     // Q = Gt L on the FP64 matrix cores (the product helper of the sign-function clip; result in the X overlay, which
     // is free here): as a 2 d-read loop per thread it was LDS-bound, 14 k of the 78 k clocks of an evaluation at n = 5
-    cd* Q = c.Vimg();
-    SignClipWG<d, NT>::matmul(A, c.L(), Q);
-    const cd q = Q[c.pi * LD + c.pj];
+    cd q{0.0, 0.0};
+    if constexpr (NQ >= 5) {
+      cd* Q = c.Vimg();
+      SignClipWG<d, NT>::matmul(A, c.L(), Q);
+      q = Q[c.pi * LD + c.pj];
+    } else {  // d = 16: the 16-term loop is cheaper than a product with its barrier (measured: 0.101 vs 0.122 ms per 1024)
+      const cd* L = c.L();
+#pragma unroll 8
+      for (int k = 0; k < d; ++k) {  // all k (L[k][pj] = 0 for k < pj): a fixed trip count can be pipelined
+        const cd u = A[c.pi * LD + k], v = L[k * LD + c.pj];
+        q.re = fma(u.re, v.re, fma(-u.im, v.im, q.re));
+        q.im = fma(u.re, v.im, fma(u.im, v.re, q.im));
+      }
+    }
     gt = 2.0 * (c.pkind == 2 ? q.im : q.re);
     __syncthreads();
     QT_STAMP(18);
@@ -790,7 +801,20 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large_bfgs(PovmView pv, c
   const int eval_cap = (max_iter + 2) * 130;
   while (true) {  // uniform: one trial per workgroup, every thread holds the same scalars
     double ft, gt;
-    S::nll_grad(c, xk + stp * pk, ft, gt);  // (barriers inside publish the parked line-search state)
+    // Inlined, with the LDS base laundered through an empty asm every iteration: the compiler can then neither hoist
+    // the ~100 loop-invariant LDS addresses of the evaluation out of the loop (that is what spilled 1.4 KB per lane
+    // when it was first inlined) nor does the kernel pay the callee-saved-register saves of an out-of-line call
+    // (224 / 288 bytes of scratch per lane).
+    // (n = 5, capped at 128 VGPRs by its 1024-thread workgroup, spills 159 VGPRs that way and keeps the call.)
+    if constexpr (NQ == 4) {
+      typename S::Ctx ci = c;
+      int off = 0;
+      asm volatile("" : "+s"(off));
+      ci.sm = c.sm + off;
+      S::nll_grad_inl(ci, xk + stp * pk, ft, gt);  // (barriers inside publish the parked line-search state)
+    } else {
+      S::nll_grad(c, xk + stp * pk, ft, gt);
+    }
     if (++nfev > eval_cap) {
       status = 2;
       break;

@@ -61,24 +61,25 @@ struct SignClipWG {
       const int tile = wave >> 1, part = wave & 1;
       const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
       const int r16 = lane & 15, kq = lane >> 4;
-      // two accumulators (one per real product): two independent MFMA chains per wavefront instead of one
-      sc_v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      // (one accumulator: a second chain -- one per real product -- was measured: no change at d = 32, and the 16 x 16
+      //  kernels came out 20 % slower end to end, k_mle_large_start<4> 0.100 -> 0.123 ms per 1024)
+      sc_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
       const cd* ap = A + (row0 + r16) * P + kq;
       const cd* bp = B + kq * P + col0 + r16;
 #pragma unroll
       for (int k0 = 0; k0 < d; k0 += 4) {
         const cd a = ap[k0], b = bp[k0 * P];
         if (part == 0) {
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, acc1, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, acc, 0, 0, 0);
         } else {
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, acc1, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, acc, 0, 0, 0);
         }
       }
       double* cdst = reinterpret_cast<double*>(C) + part;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cdst[((row0 + kq + 4 * r) * P + col0 + r16) * 2] = acc0[r] + acc1[r];
+      for (int r = 0; r < 4; ++r) cdst[((row0 + kq + 4 * r) * P + col0 + r16) * 2] = acc[r];
     }
     __syncthreads();
   }

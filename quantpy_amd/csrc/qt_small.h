@@ -578,28 +578,60 @@ struct Small {
     }
     if (!pf.seg) pf.ns[0] = pv.Ns ? pv.Ns[l < pv.S ? l : pv.S - 1] : 0.0;
   }
-  // sum over the aligned group of KK neighbouring lanes this lane belongs to (KK = 2, 4, 8, 16)
-  __device__ __forceinline__ static double segsum(double v, int KK) {
+  // sum over the aligned group of KK neighbouring lanes, KK a compile-time constant (no branch per step)
+  template <int KK>
+  __device__ __forceinline__ static double segsum_c(double v) {
     v += dpp_f64<0xB1>(v);
     if (KK >= 4) v += dpp_f64<0x4E>(v);
     if (KK >= 8) v += dpp_f64<0x141>(v);
     if (KK >= 16) v += dpp_f64<0x140>(v);
     return v;
   }
-  // Returns false when the trial's per-setting totals are not proportional to the registered shots.
+  template <int KK>
+  __device__ __forceinline__ static bool seg_check(const double (&dv)[4], const bool (&valid)[4], double total,
+                                                   const Prefetch& pf, double ns_tot) {
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bad |= valid[q] & !shots_match(segsum_c<KK>(dv[q]), total, pf.ns[q], ns_tot);
+    return bad;
+  }
   __device__ static bool load_freq(const Ctx& c, const int64_t* counts, const Prefetch* pf = nullptr) {
     // one coalesced pass over the counts: values parked in rbuf
     double part = 0.0;
     double* raw = c.rbuf();
+    double* fq = c.freq();
+    bool bad = false;
+    double total, inv;
     if (pf && pf->ok) {
+      // The prefetched path (M <= 4 G: every built-in POVM at n <= 3) is written WITHOUT branches: out-of-range rows
+      // carry 0.0 and go to one dummy slot behind raw[] (the first word of freq[], overwritten below), the frequency
+      // pass re-writes row M - 1 from the lanes beyond it, and the shots check is a compile-time butterfly per K.  As
+      // `if (m < M)` blocks and a run-time K it compiled to ~25 scalar branches on the critical path of a lone wave.
+      double dv[4];
+      bool valid[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int m = c.l + q * G;
-        if (m < c.M) {
-          const double v = (double)pf->v[q];
-          raw[m] = v;
-          part += v;
+        valid[q] = m < c.M;
+        dv[q] = valid[q] ? (double)pf->v[q] : 0.0;
+        raw[valid[q] ? m : c.Mp] = dv[q];
+        part += dv[q];
+      }
+      total = gsum<G>(part);
+      inv = 1.0 / total;
+      if (pf->seg) {  // (uniform) the K outcomes of a setting are K neighbouring lanes of one prefetched value
+        switch (c.pv.K) {
+          case 2: bad = seg_check<2>(dv, valid, total, *pf, c.pv.ns_tot); break;
+          case 4: bad = seg_check<4>(dv, valid, total, *pf, c.pv.ns_tot); break;
+          case 8: bad = seg_check<8>(dv, valid, total, *pf, c.pv.ns_tot); break;
+          default: bad = seg_check<16>(dv, valid, total, *pf, c.pv.ns_tot); break;
         }
+      }
+      wave_sync();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = c.l + q * G, mc = m < c.M ? m : c.M - 1;
+        fq[mc] = raw[c.prod() ? c.trmap[mc] : mc] * inv;
       }
     } else {
       for (int m = c.l; m < c.M; m += G) {
@@ -607,26 +639,18 @@ struct Small {
         raw[m] = v;
         part += v;
       }
-    }
-    const double total = gsum<G>(part);
-    const double inv = 1.0 / total;
-    wave_sync();
-    if (c.prod()) {
-      for (int m = c.l; m < c.M; m += G) c.freq()[m] = raw[c.trmap[m]] * inv;
-    } else {
-      for (int m = c.l; m < c.M; m += G) c.freq()[m] = raw[m] * inv;
-    }
-    // shots check (state.py:138-141, 194-197): per-setting totals against the registered N_s
-    bool bad = false;
-    if (pf && pf->seg) {  // the K outcomes of a setting are K neighbouring lanes of one prefetched value: DPP adds
-      const int K = c.pv.K;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int m = c.l + q * G;
-        const double t = segsum(m < c.M ? (double)pf->v[q] : 0.0, K);
-        bad |= m < c.M && !shots_match(t, total, pf->ns[q], c.pv.ns_tot);
+      total = gsum<G>(part);
+      inv = 1.0 / total;
+      wave_sync();
+      if (c.prod()) {
+        for (int m = c.l; m < c.M; m += G) fq[m] = raw[c.trmap[m]] * inv;
+      } else {
+        for (int m = c.l; m < c.M; m += G) fq[m] = raw[m] * inv;
       }
-    } else if (c.pv.Ns) {  // general shape: lane s sums the K outcomes of setting s (raw is in (S, K) order)
+    }
+    // shots check (state.py:138-141, 194-197) for the shapes the butterfly does not cover: lane s sums the K outcomes
+    // of setting s (raw is in the caller's (S, K) order)
+    if (c.pv.Ns && !(pf && pf->seg)) {
       const int K = c.pv.K;
       for (int s = c.l; s < c.pv.S; s += G) {
         double t = 0.0;

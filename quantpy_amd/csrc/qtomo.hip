@@ -267,9 +267,8 @@ int prepare_large(qt_handle_t* h, bool needs_lin) {
     if (h->nq == 4) {                                                                                       \
       size_t lds_ = qt::Large<4>::lds_bytes(M_, R1_, XTRA_);                                                \
       if (lds_ > kLdsLimit) return fail(QT_ERR_UNSUPPORTED, "POVM too large for LDS (%zu B)", lds_);         \
-      const bool cache_ = h->prod.enabled && h->ns_max < 4294967296.0 && lds_ + 4 * (size_t)(M_) + 8 <= kLdsLimit; \
-      if (cache_) lds_ += 4 * (size_t)(M_) + 8;                                                             \
-      h->lds_extra = cache_ ? (int)((lds_ - 4 * (size_t)(M_) - 8) / 8) : 0;                                 \
+      const bool cache_ = false; /* n = 4: measured slower with the cache (0.122 vs 0.101 ms per 1024 'mle') */ \
+      h->lds_extra = 0;                                                                                     \
       if (int r_ = allow_big_lds(KERNEL<4>, lds_)) return r_;                                               \
       hipLaunchKernelGGL((KERNEL<4>), dim3(B_), dim3(qt::Large<4>::NT), lds_, h->stream, QT_UNPACK ARGS);   \
       h->lds_extra = 0;                                                                                     \

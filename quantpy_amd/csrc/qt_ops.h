@@ -565,6 +565,41 @@ __global__ void __launch_bounds__(64) k_hs_dist(int d, const double* __restrict_
   }
 }
 
+// ---- a16: interval.py:610  dist.sort() for small n (<= 8192: every bootstrap the reference's defaults produce) ----
+// One workgroup, bitonic network in LDS on order-preserving 64-bit keys (sign-flipped IEEE bits: the order of a radix
+// sort, NaN last like np.sort).  A device radix sort is five launches for any n; this is one, ~10 us at n = 2048.
+__global__ void __launch_bounds__(1024) k_sort_small(double* __restrict__ x, int n, int npow2) {
+  extern __shared__ unsigned long long keys[];
+  for (int e = threadIdx.x; e < npow2; e += blockDim.x) {
+    unsigned long long k = ~0ull;  // padding sorts behind everything
+    if (e < n) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(x[e]);
+      k = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    }
+    keys[e] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npow2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < npow2 / 2; t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == up) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const unsigned long long k = keys[e];
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    x[e] = __longlong_as_double((long long)b);
+  }
+}
+
 // ---- a16: interval.py:610-612  interp1d(linspace(0, 1, n), sorted_dist)(conf_levels) -------------
 // scipy's linear interp1d: hi = searchsorted(x, q) clipped to [1, n-1], lo = hi - 1,
 // y = (y_hi - y_lo) / (x_hi - x_lo) * (q - x_lo) + y_lo, with x_i = i * (1 / (n - 1)) and x_(n-1) = 1 exactly

@@ -1054,6 +1054,14 @@ int qt_sort_f64(qt_handle_t* h, double* x, long long n, int flags) {
   const double* din;
   if (int r = stage_in(h, h->in0, (const double*)x, (size_t)n, flags, &din)) return r;
   double* dx = const_cast<double*>(din);
+  if (n <= 8192) {  // one workgroup, bitonic network in LDS
+    int np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    hipLaunchKernelGGL(qt::k_sort_small, dim3(1), dim3(np2 / 2 < 1024 ? (np2 / 2 < 64 ? 64 : np2 / 2) : 1024), np2 * sizeof(double),
+                       h->stream, dx, (int)n, np2);
+    if (int r = fetch_out(h, (const double*)dx, x, (size_t)n, flags)) return r;
+    return finish(h, flags);
+  }
   HIPCHK(h->sort_alt.ensure((size_t)n * sizeof(double)));
   hipcub::DoubleBuffer<double> keys(dx, h->sort_alt.as<double>());
   size_t tmp_bytes = 0;

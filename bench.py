@@ -239,7 +239,7 @@ def main():
     # ---- synthetic counts: one global legacy stream, rank r owns trials [r*B, (r+1)*B) --------
     np.random.seed(7)
     bloch = state.bloch
-    all_counts = np.stack([simulate_counts(povm, bloch, shots) for _ in range(B * world)])
+    all_counts = simulate_counts(povm, bloch, shots, repeats=B * world)  # the reference's stream order, one C call
     counts = all_counts[rank * B:(rank + 1) * B]
 
     eng = qp.get_engine(n)  # this process's GPU (torch.cuda.current_device())
@@ -383,7 +383,7 @@ def main():
         psi /= np.linalg.norm(psi)
         pure = qp.Qobj(np.outer(psi, psi.conj()))
         np.random.seed(9)
-        pure_counts = np.stack([simulate_counts(povm, pure.bloch, shots) for _ in range(B)])
+        pure_counts = simulate_counts(povm, pure.bloch, shots, repeats=B)
         # (The 1000-trial figure of the 'lin'-start case is not taken in the default run: its launches would carry the
         #  name of the timed kernel, k_mle_fused<3,false>, and skew a profiler's per-kernel average of the headline step;
         #  the fully mixed start runs as k_mle_fused_mixed.  scripts/iterating_timing.py measures both.)
@@ -465,7 +465,7 @@ def main():
         povm5 = qp.generate_measurement_matrix("proj-set", n5)
         shots5 = np.ones(povm5.shape[0]) * 10**6
         np.random.seed(7)  # the same eight count tensors on every rank (also the centre of the n = 5 bootstrap)
-        few = np.stack([simulate_counts(povm5, qp.Qobj(rho5).bloch, shots5) for _ in range(8)])
+        few = simulate_counts(povm5, qp.Qobj(rho5).bloch, shots5, repeats=8)
         b5 = 256
         e5 = qp.get_engine(n5)
         e5.set_povm(povm5, shots5)
@@ -538,8 +538,14 @@ def main():
         tmg.results = all_counts[0]
         centre = tmg.point_estimate("mle")
         np.random.seed(4242)
-        res = np.stack([simulate_counts(povm, centre.bloch, tmg.n_measurements) for _ in range(args.bootstrap_points)])
+        ts = time.perf_counter()
+        res = simulate_counts(povm, centre.bloch, tmg.n_measurements, repeats=args.bootstrap_points)
+        sample_ms = (time.perf_counter() - ts) * 1e3
         boot = bootstrap_leg(eng, res, centre.matrix, d)
+        # the resamples themselves: NumPy's legacy stream in the reference's order (one multinomial per setting per
+        # resample), drawn by qt_legacy_multinomial in one call -- serial by nature, the same on every rank
+        boot["resampling_host_ms"] = round(sample_ms, 3)
+        boot["resampling"] = "qt_legacy_multinomial: np.random's MT19937 stream, reference call order, bit-exact"
         if args.bootstrap_large > 0:
             distinct = min(args.bootstrap_large, 32768)
             pool = vector_resamples(povm, centre.bloch, tmg.n_measurements, distinct, 99)

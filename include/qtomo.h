@@ -119,6 +119,16 @@ int qt_born_probs(qt_handle_t* h, const double* bloch, int B, double* p, int fla
 int qt_bloch_from_mat(qt_handle_t* h, const double* mat, int B, double* bloch, int flags);
 int qt_mat_from_bloch(qt_handle_t* h, const double* bloch, int B, double* mat, int flags);
 
+/* ---- a4 / a12 / a16 host side: state.py:109-114, the draws behind experiment() ----------------- */
+/* rows x `np.random.multinomial(n[s], pvals[s])` with s = row % period -- NumPy's legacy sampler (MT19937 doubles,
+ * conditional binomials by BTPE / inversion) restated bit for bit on the generator state the caller passes:
+ * mt_key[624] and *mt_pos are those of `np.random.get_state()`, advanced in place by exactly the words NumPy
+ * would have consumed, so `np.random.set_state()` afterwards leaves the global stream where the reference's
+ * loop of Python calls leaves it.  pvals[period][K], out[rows][K].  Host memory only; needs no handle and no
+ * GPU.  QT_ERR_ARG (with NumPy's message) when a pvals row fails RandomState.multinomial's own checks. */
+int qt_legacy_multinomial(uint32_t* mt_key, int* mt_pos, long long rows, int period, const int64_t* n,
+                          const double* pvals, int K, int64_t* out);
+
 /* ---- a6 + a7: state.py:191-202 _point_estimate_lin, :267-273 _make_feasible ---------------- */
 /* counts[B][S][K] int64 -> rho[B][d][d][2].  physical != 0: eigenvalues clipped at 1e-15 and
  * the trace renormalised.  bloch_out (nullable): the linear-inversion Bloch vector [B][D]. */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "qt_hs_dist_batch": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int]),
     "qt_sort_f64": (_c_int, [_vp, _vp, ctypes.c_longlong, _c_int]),
     "qt_sorted_quantiles": (_c_int, [_vp, _vp, ctypes.c_longlong, _vp, _c_int, _vp, _c_int]),
+    "qt_legacy_multinomial": (_c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp]),
     "qt_process_setup": (_c_int, [_vp, _vp, _c_int]),
     "qt_process_get_operators": (_c_int, [_vp, _vp, _vp, _c_int]),
     "qt_lifp_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _c_int]),

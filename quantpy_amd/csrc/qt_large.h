@@ -706,8 +706,12 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_nll_large(PovmView pv, const 
 //   k_mle_large_bfgs: scipy's BFGS loop for the trials that iterate (workgroups of finished trials leave at once).
 //     `pairs` = nb x max_iter x 2 x D doubles of workspace ((s_i, y_i) of every accepted step); LDS carries rho_i and
 //     the two-loop alphas (2 x max_iter doubles) and, across each out-of-line evaluation, the line-search state.
+// Four wavefronts per SIMD (128 registers, AGPRs of the sign-clip MFMA included): at n = 4 the allocator otherwise
+// settles on 122 + 8, one past the step, three workgroups per CU instead of four and 20 % slower (A/B in
+// profiles/round2_n4_start_occupancy.txt); at n = 5 the 1024-thread workgroup implies the same cap.
 template <int NQ>
-__global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large_start(PovmView pv, const int64_t* __restrict__ counts, int B,
+__global__ void __launch_bounds__(Large<NQ>::NT) __attribute__((amdgpu_waves_per_eu(4)))
+k_mle_large_start(PovmView pv, const int64_t* __restrict__ counts, int B,
                                                                    int init, int max_iter, double gtol,
                                                                    double* __restrict__ rho, int32_t* __restrict__ nit_out,
                                                                    int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,

@@ -1,0 +1,199 @@
+// a4 / a12 / a16 host side: the multinomial sampler behind `experiment()` (reference state.py:109-114:
+// `np.random.multinomial(n_s, p_s)` per POVM setting on NumPy's global legacy stream).
+//
+// The draws themselves are a third-party algorithm: NumPy's legacy `RandomState.multinomial` (numpy 2.2,
+// numpy/random/mtrand.pyx) -> `legacy_random_binomial` (legacy-distributions.c) -> Kachitvichyanukul & Schmeiser's
+// BTPE rejection sampler above n p = 30 and sequential inversion below, both fed by 53-bit doubles built from two
+// MT19937 words.  The reference spends one Python call per setting and resample on it (0.9 ms per experiment at
+// n = 3; 68 of the 70 ms of a 2000-resample bootstrap CI); this file restates the published
+// algorithm so that a whole bootstrap's draws are one C loop on the SAME stream: it takes the 624-word MT19937 key
+// and position of `np.random.get_state()`, consumes exactly the words NumPy would, and hands the advanced state
+// back for `np.random.set_state()`.  tests/test_host_logic.py pins it bit for bit against numpy.random itself
+// (counts and final generator state) over the (n, p) regimes the two branches cover.
+//
+// Plain host C++ -- no device code, no handle; compiled into libqtomo.so because that is the C ABI the drop-in
+// binds.  Floating-point contraction is off in here: every product and sum rounds as NumPy's build rounds it.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+namespace qt_sampler {
+
+#pragma clang fp contract(off)
+
+struct Mt19937 {
+  uint32_t* key;  // [624], updated in place
+  int pos;        // 0..624 (624 = the block is used up)
+};
+
+inline void mt_refill(Mt19937& g) {
+  constexpr int N = 624, M = 397;
+  constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAG = 0x9908b0dfu;
+  uint32_t* k = g.key;
+  for (int i = 0; i < N; ++i) {
+    const uint32_t y = (k[i] & UPPER) | (k[(i + 1) % N] & LOWER);
+    k[i] = k[(i + M) % N] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+  }
+  g.pos = 0;
+}
+
+inline uint32_t mt_next(Mt19937& g) {
+  if (g.pos >= 624) mt_refill(g);
+  uint32_t y = g.key[g.pos++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+// the legacy 53-bit double: 27 high bits of one word, 26 of the next
+inline double mt_double(Mt19937& g) {
+  const int32_t a = (int32_t)(mt_next(g) >> 5), b = (int32_t)(mt_next(g) >> 6);
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+// The set-up constants of one (n, p): NumPy caches them in RandomState._binomial; they are pure functions of
+// (n, p), so a local cache gives the same draws.
+struct BinomialSetup {
+  bool valid = false;
+  int64_t n = 0;
+  double p = 0.0;
+  // inversion
+  double q, qn, np;
+  int64_t bound;
+  // BTPE
+  double r, fm, xm, xl, xr, c, laml, lamr, p1, p2, p3, p4;
+  int64_t m;
+  bool btpe = false;
+};
+
+// n p <= 30: walk the mass function from 0 upwards; restart with a fresh uniform past `bound`
+inline int64_t binomial_inversion(Mt19937& g, int64_t n, double p, BinomialSetup& s) {
+  if (!s.valid || s.btpe || s.n != n || s.p != p) {
+    s.valid = true, s.btpe = false, s.n = n, s.p = p;
+    s.q = 1.0 - p;
+    s.qn = exp(n * log(s.q));
+    s.np = n * p;
+    const double lim = s.np + 10.0 * sqrt(s.np * s.q + 1);
+    s.bound = (int64_t)((double)n < lim ? (double)n : lim);
+  }
+  const double q = s.q, qn = s.qn;
+  const int64_t bound = s.bound;
+  int64_t x = 0;
+  double px = qn, u = mt_double(g);
+  while (u > px) {
+    ++x;
+    if (x > bound) {
+      x = 0;
+      px = qn;
+      u = mt_double(g);
+    } else {
+      u -= px;
+      px = ((n - x + 1) * p * px) / (x * q);
+    }
+  }
+  return x;
+}
+
+// n p > 30 (p <= 0.5): BTPE -- triangle, parallelogram and two exponential tails as the envelope, then the
+// squeeze / exact acceptance tests of the published algorithm
+inline int64_t binomial_btpe(Mt19937& g, int64_t n, double p, BinomialSetup& s) {
+  if (!s.valid || !s.btpe || s.n != n || s.p != p) {
+    s.valid = true, s.btpe = true, s.n = n, s.p = p;
+    s.r = p < 1.0 - p ? p : 1.0 - p;
+    s.q = 1.0 - s.r;
+    s.fm = n * s.r + s.r;
+    s.m = (int64_t)floor(s.fm);
+    s.p1 = floor(2.195 * sqrt(n * s.r * s.q) - 4.6 * s.q) + 0.5;
+    s.xm = s.m + 0.5;
+    s.xl = s.xm - s.p1;
+    s.xr = s.xm + s.p1;
+    s.c = 0.134 + 20.5 / (15.3 + s.m);
+    double a = (s.fm - s.xl) / (s.fm - s.xl * s.r);
+    s.laml = a * (1.0 + a / 2.0);
+    a = (s.xr - s.fm) / (s.xr * s.q);
+    s.lamr = a * (1.0 + a / 2.0);
+    s.p2 = s.p1 * (1.0 + 2.0 * s.c);
+    s.p3 = s.p2 + s.c / s.laml;
+    s.p4 = s.p3 + s.c / s.lamr;
+  }
+  const double r = s.r, q = s.q, xm = s.xm, xl = s.xl, xr = s.xr, c = s.c, laml = s.laml, lamr = s.lamr;
+  const double p1 = s.p1, p2 = s.p2, p3 = s.p3, p4 = s.p4;
+  const int64_t m = s.m;
+  const double nrq = n * r * q;
+  int64_t y;
+  for (;;) {
+    const double u = mt_double(g) * p4;
+    double v = mt_double(g);
+    if (u <= p1) {  // triangle: accepted at once
+      y = (int64_t)floor(xm - p1 * v + u);
+      break;
+    }
+    if (u <= p2) {  // parallelogram
+      const double x = xl + (u - p1) / c;
+      v = v * c + 1.0 - fabs(m - x + 0.5) / p1;
+      if (v > 1.0) continue;
+      y = (int64_t)floor(x);
+    } else if (u <= p3) {  // left tail
+      y = (int64_t)floor(xl + log(v) / laml);
+      if (y < 0 || v == 0.0) continue;
+      v = v * (u - p2) * laml;
+    } else {  // right tail
+      y = (int64_t)floor(xr - log(v) / lamr);
+      if (y > n || v == 0.0) continue;
+      v = v * (u - p3) * lamr;
+    }
+    const int64_t k = y > m ? y - m : m - y;
+    if (!(k > 20 && k < nrq / 2.0 - 1)) {  // near the mode or far out: the exact ratio f(y) / f(m) by recursion
+      const double sq = r / q, a = sq * (n + 1);
+      double f = 1.0;
+      if (m < y) {
+        for (int64_t i = m + 1; i <= y; ++i) f *= (a / i - sq);
+      } else if (m > y) {
+        for (int64_t i = y + 1; i <= m; ++i) f /= (a / i - sq);
+      }
+      if (v > f) continue;
+      break;
+    }
+    // squeeze on log v, then the Stirling-corrected bound
+    const double rho = (k / nrq) * ((k * (k / 3.0 + 0.625) + 0.16666666666666666) / nrq + 0.5);
+    const double t = -k * k / (2 * nrq);
+    const double lv = log(v);
+    if (lv < t - rho) break;
+    if (lv > t + rho) continue;
+    const double x1 = y + 1, f1 = m + 1, z = n + 1 - m, w = n - y + 1;
+    const double x2 = x1 * x1, f2 = f1 * f1, z2 = z * z, w2 = w * w;
+    const double limit = xm * log(f1 / x1) + (n - m + 0.5) * log(z / w) + (y - m) * log(w * r / (x1 * q)) +
+                         (13680. - (462. - (132. - (99. - 140. / f2) / f2) / f2) / f2) / f1 / 166320. +
+                         (13680. - (462. - (132. - (99. - 140. / z2) / z2) / z2) / z2) / z / 166320. +
+                         (13680. - (462. - (132. - (99. - 140. / x2) / x2) / x2) / x2) / x1 / 166320. +
+                         (13680. - (462. - (132. - (99. - 140. / w2) / w2) / w2) / w2) / w / 166320.;
+    if (lv > limit) continue;
+    break;
+  }
+  return y;  // the caller only comes here with p <= 0.5: no reflection left to do
+}
+
+inline int64_t legacy_binomial(Mt19937& g, double p, int64_t n, BinomialSetup& s) {
+  if (n == 0 || p == 0.0) return 0;  // no word consumed (RandomState.multinomial shares random_binomial's early exit)
+  if (p <= 0.5) return p * n <= 30.0 ? binomial_inversion(g, n, p, s) : binomial_btpe(g, n, p, s);
+  const double q = 1.0 - p;
+  return n - (q * n <= 30.0 ? binomial_inversion(g, n, q, s) : binomial_btpe(g, n, q, s));
+}
+
+// one RandomState.multinomial(n, pvals) row: conditional binomials, first to last-but-one category
+inline void legacy_multinomial(Mt19937& g, int64_t n, const double* pvals, int K, int64_t* out, BinomialSetup* cache) {
+  double remaining_p = 1.0;
+  int64_t dn = n;
+  for (int j = 0; j < K; ++j) out[j] = 0;
+  for (int j = 0; j < K - 1; ++j) {
+    out[j] = legacy_binomial(g, pvals[j] / remaining_p, dn, cache[j]);
+    dn -= out[j];
+    if (dn <= 0) break;
+    remaining_p -= pvals[j];
+  }
+  if (dn > 0) out[K - 1] = dn;
+}
+
+}  // namespace qt_sampler

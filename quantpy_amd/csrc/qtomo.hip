@@ -16,6 +16,7 @@
 #include "qt_large.h"
 #include "qt_ops.h"
 #include "qt_process.h"
+#include "qt_sampler.h"
 #include "qt_small.h"
 
 namespace {
@@ -1088,6 +1089,38 @@ int qt_sorted_quantiles(qt_handle_t* h, const double* sorted, long long n, const
   hipLaunchKernelGGL(qt::k_interp_sorted, dim3((n_levels + 255) / 256), dim3(256), 0, h->stream, ds, n, dq, n_levels, dout);
   if (int r = fetch_out(h, dout, out, (size_t)n_levels, flags)) return r;
   return finish(h, flags);
+}
+
+// ---- a4 / a12 / a16 host side: state.py:109-114, the draws of experiment() (qt_sampler.h) ---------
+int qt_legacy_multinomial(uint32_t* mt_key, int* mt_pos, long long rows, int period, const int64_t* n,
+                          const double* pvals, int K, int64_t* out) {
+  if (!mt_key || !mt_pos || !n || !pvals || (rows > 0 && !out) || rows < 0 || period < 1 || K < 1)
+    return fail(QT_ERR_ARG, "bad legacy_multinomial arguments");
+  if (*mt_pos < 0 || *mt_pos > 624) return fail(QT_ERR_ARG, "MT19937 position %d outside 0..624", *mt_pos);
+  for (int s = 0; s < period; ++s) {
+    if (n[s] < 0) return fail(QT_ERR_ARG, "n < 0 in row %d", s);
+    // RandomState.multinomial's own checks (mtrand.pyx): every pval in [0, 1], and the leading K - 1 may not exceed 1
+    double head = 0.0, comp = 0.0;  // compensated sum, as NumPy's check has it
+    for (int j = 0; j < K; ++j) {
+      const double p = pvals[(size_t)s * K + j];
+      if (!(p >= 0.0 && p <= 1.0)) return fail(QT_ERR_ARG, "pvals < 0, pvals > 1 or pvals contains NaNs");
+      if (j == 0 && K > 1) head = p;
+      if (j > 0 && j < K - 1) {
+        const double y = p - comp, t = head + y;
+        comp = (t - head) - y;
+        head = t;
+      }
+    }
+    if (head > 1.0 + 1e-12) return fail(QT_ERR_ARG, "sum(pvals[:-1]) > 1.0");
+  }
+  qt_sampler::Mt19937 g{mt_key, *mt_pos};
+  std::vector<qt_sampler::BinomialSetup> cache((size_t)period * K);
+  for (long long r = 0; r < rows; ++r) {
+    const int s = (int)(r % period);
+    qt_sampler::legacy_multinomial(g, n[s], pvals + (size_t)s * K, K, out + (size_t)r * K, cache.data() + (size_t)s * K);
+  }
+  *mt_pos = g.pos;
+  return 0;
 }
 
 // ---- a5 for arbitrary matrices: routines.py:69-71 -------------------------------------------------

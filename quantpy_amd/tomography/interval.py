@@ -160,11 +160,10 @@ class BootstrapStateInterval(ConfidenceInterval):
                 self.state = tmg.point_estimate(method=self.method, physical=self.physical, init=self.init,
                                                 tol=self.tol, max_iter=self.max_iter)
         boot = tmg.__class__(self.state, tmg.dst)
-        counts = []
-        for _ in range(self.n_points):  # serial on purpose: one global RNG stream, reference order
-            boot.experiment(tmg.n_measurements, tmg.povm_matrix)
-            counts.append(boot.results)
-        counts = qdist.broadcast_array(np.stack(counts)) if self.n_points else np.empty((0,) + tmg.results.shape)
+        # every resample's counts, one global RNG stream in the reference's order (resample after resample, setting
+        # after setting): ONE call of the C restatement of NumPy's sampler instead of n_points x S Python calls
+        counts = boot.experiment_batch(tmg.n_measurements, tmg.povm_matrix, self.n_points)
+        counts = qdist.broadcast_array(counts) if self.n_points else np.empty((0,) + tmg.results.shape)
         self.boot_counts = counts
         centre = self.state
 
@@ -403,11 +402,7 @@ class BootstrapProcessInterval(ConfidenceInterval):
                                                   states_init=self.states_init, cptp=self.cptp)
         boot = tmg.__class__(self.channel, tmg.input_states, tmg.dst)
         shots, povm = tmg.tomographs[0].n_measurements, tmg.tomographs[0].povm_matrix
-        counts = []
-        for _ in range(self.n_points):
-            boot.experiment(shots, povm=povm)
-            counts.append(boot.results)
-        counts = qdist.broadcast_array(np.stack(counts))
+        counts = qdist.broadcast_array(boot.experiment_batch(shots, povm=povm, repeats=self.n_points))
         self.boot_counts = counts
         centre = self.channel.choi
 

@@ -14,7 +14,8 @@ from ..engine import get_engine
 from ..measurements import generate_measurement_matrix
 from ..qobj import Qobj
 from ..routines import _mat2vec, _out_ptrace_oper, _vec2mat, generate_single_entries
-from .state import StateTomograph, _resolve_dst
+from ..sampling import legacy_multinomial
+from .state import StateTomograph, _resolve_dst, born_probabilities
 
 
 def _generate_input_states(input_states, n_qubits):
@@ -59,6 +60,21 @@ class ProcessTomograph:
             self.tomographs = [StateTomograph(self.channel.transform(state)) for state in self.input_basis.elements]
         for tmg in self.tomographs:
             tmg.experiment(n_measurements, povm, warm_start=warm_start)
+
+    def experiment_batch(self, n_measurements, povm="proj-set", repeats=1):
+        """Counts (repeats, n_inputs, S, K) of `repeats` successive `experiment(n_measurements, povm)` calls, drawn in
+        one call in the same order on the same global stream (resample, input state, setting: the loop of reference
+        interval.py:673-676).  Leaves the tomographs as the last of those calls would."""
+        self.tomographs = [StateTomograph(self.channel.transform(state)) for state in self.input_basis.elements]
+        first = self.tomographs[0]
+        povm_matrix, shots = first._experiment_arguments(n_measurements, povm)
+        probas = np.concatenate([born_probabilities(povm_matrix, tmg.state.bloch) for tmg in self.tomographs])
+        n_in, n_set = len(self.tomographs), povm_matrix.shape[0]
+        counts = legacy_multinomial(np.tile(shots, n_in), probas, repeats).reshape(repeats, n_in, n_set, -1)
+        if repeats:
+            for tmg, last in zip(self.tomographs, counts[-1]):
+                tmg.povm_matrix, tmg.results, tmg.n_measurements = povm_matrix, last, np.asarray(shots)
+        return counts
 
     @property
     def results(self):

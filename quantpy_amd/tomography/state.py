@@ -11,6 +11,7 @@ from ..engine import get_engine
 from ..geometry import hs_dst, if_dst, trace_dst
 from ..measurements import generate_measurement_matrix
 from ..qobj import Qobj
+from ..sampling import legacy_multinomial
 
 _DISTANCES = {"hs": hs_dst, "trace": trace_dst, "if": if_dst}
 
@@ -23,19 +24,23 @@ def _resolve_dst(dst):
     return dst
 
 
-def simulate_counts(povm_matrix, bloch, n_measurements):
-    """Born probabilities + multinomial draws for one state (reference state.py:109-114).
-
-    The probabilities that feed the sampler are evaluated on the host with the reference's own
-    NumPy expression: the legacy binomial behind np.random.multinomial branches on p <= 0.5, and
-    structured states put conditional probabilities exactly there, so the last bit of p decides
-    the draw.  (The GPU Born-rule kernel qt_born_probs serves batched probability evaluation,
-    where that bit does not matter.)
-    """
+def born_probabilities(povm_matrix, bloch):
+    """p[s, k] that feed the sampler (reference state.py:109-111), evaluated on the host with the reference's own
+    NumPy expression: the binomial sampler behind np.random.multinomial branches on p <= 0.5, and structured states
+    put conditional probabilities exactly there, so the last bit of p decides the draw.  (The GPU Born-rule kernel
+    qt_born_probs serves batched probability evaluation, where that bit does not matter.)"""
     dim = int(round(np.sqrt(povm_matrix.shape[-1])))
     probas = np.einsum("ijk,k->ij", povm_matrix, bloch) * dim
-    probas = np.clip(probas, 0, 1)
-    return np.asarray([np.random.multinomial(n, p) for p, n in zip(probas, n_measurements)])
+    return np.clip(probas, 0, 1)
+
+
+def simulate_counts(povm_matrix, bloch, n_measurements, repeats=None):
+    """Born probabilities + multinomial draws for one state (reference state.py:109-114): one draw per POVM setting,
+    in order, on NumPy's global legacy stream -- made by `qt_legacy_multinomial`, which restates NumPy's sampler bit
+    for bit, so a seed reproduces the reference's counts and leaves `np.random` where the reference leaves it.
+    `repeats=R` gives the (R, S, K) counts of R successive experiments (a bootstrap's resamples) from one call."""
+    counts = legacy_multinomial(n_measurements, born_probabilities(povm_matrix, bloch), 1 if repeats is None else repeats)
+    return counts[0] if repeats is None else counts
 
 
 class StateTomograph:
@@ -56,6 +61,15 @@ class StateTomograph:
         self._results = None
 
     # ---- data ---------------------------------------------------------------------------------
+    def _experiment_arguments(self, n_measurements, povm):
+        povm_matrix = generate_measurement_matrix(povm, self.state.n_qubits)
+        n_settings = povm_matrix.shape[0]
+        if np.issubdtype(type(n_measurements), np.integer):
+            n_measurements = np.ones(n_settings) * n_measurements
+        elif len(n_measurements) != n_settings:
+            raise ValueError("Wrong length for argument `n_measurements`")
+        return povm_matrix, n_measurements
+
     def experiment(self, n_measurements, povm="proj-set", warm_start=False):
         """Draw measurement outcomes.
 
@@ -64,12 +78,7 @@ class StateTomograph:
         povm : name or array, see `generate_measurement_matrix`.
         warm_start : append to the data of the previous call instead of replacing it.
         """
-        povm_matrix = generate_measurement_matrix(povm, self.state.n_qubits)
-        n_settings = povm_matrix.shape[0]
-        if np.issubdtype(type(n_measurements), np.integer):
-            n_measurements = np.ones(n_settings) * n_measurements
-        elif len(n_measurements) != n_settings:
-            raise ValueError("Wrong length for argument `n_measurements`")
+        povm_matrix, n_measurements = self._experiment_arguments(n_measurements, povm)
         counts = simulate_counts(povm_matrix, self.state.bloch, n_measurements)
         if warm_start:
             old_total, new_total = np.sum(self.n_measurements), np.sum(n_measurements)
@@ -79,6 +88,18 @@ class StateTomograph:
             self.povm_matrix = povm_matrix
             self.results = counts
             self.n_measurements = np.asarray(n_measurements)
+
+    def experiment_batch(self, n_measurements, povm="proj-set", repeats=1):
+        """The counts (repeats, S, K) of `repeats` successive `experiment(n_measurements, povm)` calls -- same global
+        stream, same order -- drawn in one call (the resampling loop of a bootstrap, reference interval.py:598-604).
+        Leaves the tomograph as the last of those calls would."""
+        povm_matrix, n_measurements = self._experiment_arguments(n_measurements, povm)
+        counts = simulate_counts(povm_matrix, self.state.bloch, n_measurements, repeats=repeats)
+        if repeats:
+            self.povm_matrix = povm_matrix
+            self.results = counts[-1]
+            self.n_measurements = np.asarray(n_measurements)
+        return counts
 
     @property
     def results(self):

@@ -308,3 +308,99 @@ def test_header_is_plain_c(tmp_path):
     out = tmp_path / "abi_header_check.o"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", src, "-o", str(out)])
     assert out.exists()
+
+
+def _numpy_draws(n, p, repeats):
+    """The reference's sampling loop itself (state.py:112 inside interval.py:598-604): numpy.random is the checker."""
+    return np.asarray([[np.random.multinomial(int(n_s), p_s) for p_s, n_s in zip(p, n)] for _ in range(repeats)])
+
+
+def test_c_sampler_is_numpys_legacy_multinomial_bit_for_bit():
+    """qt_legacy_multinomial (csrc/qt_sampler.h) against numpy.random.multinomial on the same MT19937 state: the
+    counts AND the generator state afterwards (so whatever the caller draws next is unchanged too).  The sweep
+    covers both binomial branches (inversion at n p <= 30, BTPE above), the p > 0.5 reflection, exact zeros and
+    ones in p, n = 0, categories that exhaust n early, and generator positions either side of a 624-word refill."""
+    from quantpy_amd.sampling import legacy_multinomial
+
+    rng = np.random.default_rng(1)
+    for trial in range(300):
+        n_set, n_out = int(rng.integers(1, 6)), int(rng.integers(1, 9))
+        kind = trial % 5
+        p = rng.random((n_set, n_out)) ** (1 + 3 * (kind == 1))
+        if kind == 2:
+            p[rng.random((n_set, n_out)) < 0.4] = 0
+        p[:, 0] += 1e-9
+        p /= p.sum(1, keepdims=True)
+        if kind == 4 and n_out > 1:
+            p[0] = 0
+            p[0, int(rng.integers(0, n_out))] = 1.0
+        n = rng.integers(0, [10, 100, 10**4, 10**6, 10**9][trial % 5], n_set)
+        repeats = int(rng.integers(1, 30))
+        np.random.seed(int(rng.integers(0, 2**31)))
+        np.random.rand(int(rng.integers(0, 700)))
+        start = np.random.get_state()
+        want = _numpy_draws(n, p, repeats)
+        want_state = np.random.get_state()
+        np.random.set_state(start)
+        got = legacy_multinomial(n, p, repeats)
+        got_state = np.random.get_state()
+        assert got.dtype == np.int64 and np.array_equal(got, want), (trial, n, p)
+        assert got_state[2] == want_state[2] and np.array_equal(got_state[1], want_state[1]), trial
+        assert got_state[3:] == want_state[3:]  # the cached Gaussian is not ours to touch
+
+
+def test_c_sampler_rejects_what_numpy_rejects():
+    from quantpy_amd.sampling import legacy_multinomial
+
+    np.random.seed(3)
+    before = np.random.get_state()
+    for bad in ([[0.5, 0.6, 0.1]], [[-0.1, 0.6, 0.5]], [[np.nan, 0.5, 0.5]]):
+        with pytest.raises(ValueError):
+            np.random.multinomial(10, bad[0])
+        with pytest.raises(ValueError):
+            legacy_multinomial([10], bad)
+    after = np.random.get_state()
+    assert after[2] == before[2] and np.array_equal(after[1], before[1])  # nothing drawn
+
+
+def test_bootstrap_resamples_in_one_call_equal_the_reference_loop(qp, oracle):
+    """The 64 resamples tests/golden holds for a 3-qubit bootstrap (drawn by the reference's own
+    StateTomograph.experiment loop, make_golden.py:gen_bootstrap) come out of the one-call path: probabilities by
+    the reference's einsum, all draws by one qt_legacy_multinomial call."""
+    from quantpy_amd.tomography.state import simulate_counts
+
+    g = load_golden("bootstrap")
+    povm = oracle.measurement_matrix("proj-set", 3)
+    np.random.seed(4242)
+    got = simulate_counts(povm, qp.Qobj(g["B3lin_centre"]).bloch, g["B3lin_nmeas"], repeats=g["B3lin_boot_counts"].shape[0])
+    assert np.array_equal(got, g["B3lin_boot_counts"])
+    np.random.seed(4242)
+    one = simulate_counts(povm, qp.Qobj(g["B3lin_centre"]).bloch, g["B3lin_nmeas"])
+    assert one.shape == (27, 8) and np.array_equal(one, got[0])
+
+
+def test_c_sampler_other_routes_to_the_generator(monkeypatch):
+    """Same draws when the MT19937 state is copied out and back instead of advanced in place (the route taken if
+    NumPy's state layout were not the one checked for), and the reference's own loop when np.random has been given
+    a generator that is not MT19937."""
+    from quantpy_amd import sampling
+
+    p = np.random.default_rng(5).random((4, 6))
+    p /= p.sum(1, keepdims=True)
+    n = [1000, 50, 10**6, 7]
+    np.random.seed(11)
+    want = sampling.legacy_multinomial(n, p, 9)
+    want_next = np.random.rand()
+    monkeypatch.setattr(sampling, "_mt19937_address", lambda bitgen: None)
+    np.random.seed(11)
+    assert np.array_equal(sampling.legacy_multinomial(n, p, 9), want) and np.random.rand() == want_next
+    monkeypatch.undo()
+    if hasattr(np.random, "set_bit_generator"):
+        old = np.random.get_bit_generator()
+        try:
+            np.random.set_bit_generator(np.random.PCG64(3))
+            got = sampling.legacy_multinomial(n, p, 2)
+            np.random.set_bit_generator(np.random.PCG64(3))
+            assert np.array_equal(got, _numpy_draws(n, p, 2))
+        finally:
+            np.random.set_bit_generator(old)

@@ -55,6 +55,7 @@ SIGNATURES = {
     "qt_legacy_multinomial": (_c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp]),
     "qt_process_setup": (_c_int, [_vp, _vp, _c_int]),
     "qt_process_get_operators": (_c_int, [_vp, _vp, _vp, _c_int]),
+    "qt_process_get_factors": (_c_int, [_vp, _vp, _vp, _c_int]),
     "qt_lifp_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _c_int]),
     "qt_pgdb_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_dbl, _c_int, _vp, _vp, _vp, _c_int]),
     "qt_mhmc_process": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _c_int]),

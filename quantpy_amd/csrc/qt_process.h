@@ -25,9 +25,15 @@ struct ProcessState {
   void* in_states = nullptr; // [D][d][d] complex
   void* aug = nullptr;       // [D^2][2 D^2] complex Gauss-Jordan workspace
   void* pinv = nullptr;      // [D^2][D*M] complex
+  // n = 3 (qt_process64.h): the design matrix stays Kronecker-factored -- left inverses of its two factors
+  void* vs_pinv = nullptr;   // [D][D] complex: left inverse of V_S = [vec rho_s]
+  void* vp_pinv = nullptr;   // [D][M] complex: left inverse of V_P = [vec E_m] (index e d + b)
+  void* vp_pinvT = nullptr;  // [M][D] complex: its transpose, the right-hand operand of T = F V_P^+^T
+  bool factored = false;
   size_t cap_rows = 0;
   void release() {
-    for (void** p : {&lifp, &pinvT, &emats, &in_states, &aug, &pinv}) {
+    factored = false;
+    for (void** p : {&lifp, &pinvT, &emats, &in_states, &aug, &pinv, &vs_pinv, &vp_pinv, &vp_pinvT}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }

@@ -1,0 +1,396 @@
+// Process tomography of THREE qubits (reference quantpy/tomography/process.py:142-289, size-generic there):
+// 64 input states x 216 POVM rows, a 64 x 64 Choi matrix.
+//
+// Linear inversion without the 13824 x 4096 design matrix.  The reference builds rows
+//     vec(rho_s (x) E_m^T)            (process.py:203-208; 906 MB complex at n = 3)
+// and applies inv(L^T L) L^T to the frequencies (routines.py:69-71, plain transposes).  A row is the Kronecker
+// product of vec(rho_s) and vec(E_m^T) up to a fixed permutation of the columns, L = (V_S (x) V_P) Pi^T, and the
+// left inverse of a Kronecker product is the Kronecker product of the left inverses:
+//     L^+ = Pi (V_S^+ (x) V_P^+),      V_S = [vec rho_s]  64 x 64,   V_P = [vec E_m]  216 x 64   (both complex).
+// So   X = V_S^+ . F . V_P^+^T   with F[s][m] the frequencies, and  Choi[(a, b)][(c, e)] = X[(a, c)][(e, b)]:
+// two small products per process (1.1 M multiply-adds instead of 56 M) and 0.3 MB of operands instead of 1.8 GB.
+// qt_process_setup factors the design matrix this way for n = 3; k_lifp_kron_finish is the second product + the
+// index shuffle (the first one, over the whole batch, is k_gemm).
+//
+// CPTP projection (process.py:231-278) for the 64 x 64 Choi matrix: one 1024-thread workgroup per process, FOUR
+// elements per thread -- the four a wavefront's lane receives from v_mfma_f64_16x16x4_f64 for its 16 x 16 tile
+// (wavefront w <-> tile w: rows 16 (w / 4) + kq + 4 r, column 16 (w % 4) + r16) -- so the Dykstra variables x, p, q, y
+// stay in registers through the loop and the products of the CP step's sign iteration (qt_signclip_wg.h explains
+// the iteration) leave their result where the element-wise updates want it.  LDS: two 64 x 65 complex images
+// (the third image of SignClipWG is the accumulator registers here) + a column buffer for the Cholesky test.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qt_process.h"
+#include "qt_signclip_wg.h"
+
+namespace qt {
+
+struct Proc64 {
+  static constexpr int DC = 64, DQ = 8, NT = 1024, NW = NT / 64, P = DC + 1;
+  // LDS layout, offsets in doubles (all even: cd accesses are 16-byte aligned)
+  static constexpr int oImg0 = 0, oImg1 = oImg0 + 2 * DC * P, oCol = oImg1 + 2 * DC * P, oTp = oCol + 2 * 2 * DC,
+                       oRed = oTp + 2 * DC, oRed6 = oRed + 32, kDoubles = oRed6 + 6 * NW;
+  static constexpr size_t kLdsBytes = (size_t)kDoubles * sizeof(double);
+
+  struct Map {  // this thread's four elements (i[r], j)
+    int row0, col0, r16, kq, j;
+    __device__ Map() {
+      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      row0 = 16 * (w >> 2), col0 = 16 * (w & 3), r16 = lane & 15, kq = lane >> 4, j = col0 + r16;
+    }
+    __device__ __forceinline__ int i(int r) const { return row0 + kq + 4 * r; }
+  };
+
+  __device__ static double wsum(double* red, double v) {  // identical bits in every thread
+    v = gsum<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];
+    return s;
+  }
+
+  // (re, im) of this wavefront's tile of A B; no barrier inside
+  __device__ __forceinline__ static void tile_product(const cd* A, const cd* B, const Map& m, sc_v4f64& cre, sc_v4f64& cim) {
+    cre = sc_v4f64{0.0, 0.0, 0.0, 0.0};
+    cim = cre;
+    const cd* ap = A + (m.row0 + m.r16) * P + m.kq;
+    const cd* bp = B + m.kq * P + m.col0 + m.r16;
+#pragma unroll 4
+    for (int k0 = 0; k0 < DC; k0 += 4) {
+      const cd a = ap[k0], b = bp[k0 * P];
+      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, cre, 0, 0, 0);
+      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, cim, 0, 0, 0);
+      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, cre, 0, 0, 0);
+      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, cim, 0, 0, 0);
+    }
+  }
+
+  // Hermitian completion from the lower triangle (LAPACK zheevd, uplo = 'L': what numpy.linalg.eigh reads)
+  __device__ static void complete_lower(cd (&a)[4], const Map& m, double* sm) {
+    cd* X = reinterpret_cast<cd*>(sm + oImg0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[m.i(r) * P + m.j] = a[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = m.i(r);
+      if (i < m.j) {
+        const cd t = X[m.j * P + i];
+        a[r] = cd{t.re, -t.im};
+      } else if (i == m.j) {
+        a[r].im = 0.0;
+      }
+    }
+    __syncthreads();
+  }
+
+  // Does the (Hermitian) matrix have a Cholesky factorisation with every pivot above eps?  Then no eigenvalue is
+  // clipped by more than eps and the CP projection is the identity (the common case once Dykstra's iterates
+  // settle).  Right-looking elimination on the register-resident elements; only column k travels through LDS.
+  __device__ static bool is_pd(const cd (&a)[4], double eps, const Map& m, double* sm) {
+    cd w[4] = {a[0], a[1], a[2], a[3]};
+    bool pd = true;
+    for (int k = 0; k < DC; ++k) {
+      cd* col = reinterpret_cast<cd*>(sm + oCol) + (k & 1) * DC;
+      if (m.j == k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) col[m.i(r)] = w[r];
+      }
+      __syncthreads();
+      const double piv = col[k].re;
+      if (!(piv > eps)) {  // uniform: every thread reads the same pivot
+        pd = false;
+        break;
+      }
+      if (m.j > k) {
+        const double inv = 1.0 / piv;
+        const cd cj = col[m.j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (m.i(r) > k) {
+            const cd ci = col[m.i(r)];
+            w[r].re -= (ci.re * cj.re + ci.im * cj.im) * inv;  // a_ik conj(a_jk) / a_kk
+            w[r].im -= (ci.im * cj.re - ci.re * cj.im) * inv;
+          }
+        }
+      }
+    }
+    __syncthreads();  // the column buffers are free again
+    return pd;
+  }
+
+  // U max(lambda, eps) U^dagger of the Hermitian matrix whose elements a[] this thread holds (sign-function
+  // iteration of qt_signclip_wg.h; X in image 0, Y / W / A in image 1, products land in registers)
+  // `park` = 4 x NT complex of global memory for this process (element r of thread t at [r * NT + t]): the input
+  // waits there while the iteration runs, so that the loop's live registers are the product tiles and the iterate
+  __device__ static void clip(cd (&a)[4], double eps, const Map& m, double* sm, cd* park) {
+    cd* X = reinterpret_cast<cd*>(sm + oImg0);
+    cd* Y = reinterpret_cast<cd*>(sm + oImg1);
+    double* red = sm + oRed;
+    int e[4], et[4];
+    double n2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      e[r] = m.i(r) * P + m.j;
+      et[r] = m.j * P + m.i(r);
+      if (e[r] == et[r]) a[r].im = 0.0;
+      n2 += a[r].re * a[r].re + a[r].im * a[r].im;
+    }
+    const double nrm2 = wsum(red, n2);
+    if (!(nrm2 > 0.0)) {  // the zero matrix (or NaN input): every eigenvalue is clipped to eps
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = cd{nrm2 == 0.0 ? (e[r] == et[r] ? eps : 0.0) : nrm2, 0.0};
+      return;
+    }
+    const double scale = 1.0 / sqrt(nrm2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      park[r * NT + threadIdx.x] = a[r];
+      X[e[r]] = cd{a[r].re * scale, a[r].im * scale};
+    }
+    __syncthreads();
+    bool lifting = true;
+    int ns_left = 12;
+    for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (wsum returns identical bits)
+      sc_v4f64 pre, pim;
+      tile_product(X, X, m, pre, pim);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y[e[r]] = cd{pre[r], pim[r]};  // (image 1 is idle: the last product ended behind a barrier)
+      __syncthreads();
+      cd y[4];
+      double rs = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const cd yt = Y[et[r]];
+        y[r] = cd{0.5 * (pre[r] + yt.re), 0.5 * (pim[r] - yt.im)};  // Hermitian part
+        const double dr = (e[r] == et[r] ? 1.0 : 0.0) - y[r].re;
+        rs += dr * dr + y[r].im * y[r].im;
+      }
+      const double res = wsum(red, rs);  // (its first barrier also ends the transposed reads of Y)
+      if (lifting && (res < 0.5 || k >= 40)) lifting = false;
+      const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);
+      const double alpha = lifting ? 2.0 : 1.5, beta = lifting ? -1.0 : -0.5;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y[e[r]] = cd{fma(beta, y[r].re, e[r] == et[r] ? alpha : 0.0), beta * y[r].im};  // W
+      __syncthreads();
+      tile_product(X, Y, m, pre, pim);
+      __syncthreads();  // every wavefront has read X and W
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[e[r]] = cd{pre[r], pim[r]};
+      __syncthreads();
+      if (last || !(res == res)) break;
+    }
+    // S = sign(A) sits in X.  R = (A + A S) / 2 + eps (I - S) / 2
+    cd s[4];
+    asm volatile("" : "+v"(park) : : "memory");  // a real reload: without it the compiler forwards the stored registers
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a[r] = park[r * NT + threadIdx.x];
+      s[r] = X[e[r]];
+      Y[e[r]] = a[r];
+    }
+    __syncthreads();
+    sc_v4f64 pre, pim;
+    tile_product(Y, X, m, pre, pim);
+    cd out[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      out[r] = cd{0.5 * (a[r].re + pre[r]) + 0.5 * eps * ((e[r] == et[r] ? 1.0 : 0.0) - s[r].re),
+                  0.5 * (a[r].im + pim[r]) - 0.5 * eps * s[r].im};
+    __syncthreads();  // the product's reads of image 1 are done
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Y[e[r]] = out[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const cd rt = Y[et[r]];
+      a[r] = cd{0.5 * (out[r].re + rt.re), 0.5 * (out[r].im - rt.im)};
+      if (e[r] == et[r]) a[r].im = 0.0;
+    }
+    __syncthreads();
+  }
+
+  // CP projection (process.py:270-277): eigh on the lower triangle, clip at eps, rebuild
+  __device__ static void cp_project(cd (&a)[4], double eps, const Map& m, double* sm, cd* park) {
+    complete_lower(a, m, sm);
+    if (is_pd(a, eps, m, sm)) return;
+    clip(a, eps, m, sm, park);
+  }
+
+  // TP projection (process.py:259-265): C[(a,o),(b,o)] += (delta_ab - sum_o' C[(a,o'),(b,o')]) / d
+  __device__ static void tp_project(cd (&a)[4], const Map& m, double* sm) {
+    cd* X = reinterpret_cast<cd*>(sm + oImg0);
+    cd* rr = reinterpret_cast<cd*>(sm + oTp);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[m.i(r) * P + m.j] = a[r];
+    __syncthreads();
+    if (threadIdx.x < DQ * DQ) {
+      const int ia = threadIdx.x / DQ, ib = threadIdx.x % DQ;
+      double sr = 0.0, si = 0.0;
+      for (int o = 0; o < DQ; ++o) {
+        const cd t = X[(ia * DQ + o) * P + (ib * DQ + o)];
+        sr += t.re;
+        si += t.im;
+      }
+      rr[threadIdx.x] = cd{sr, si};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = m.i(r), ia = i / DQ, o = i % DQ, ib = m.j / DQ, o2 = m.j % DQ;
+      if (o == o2) {
+        const cd t = rr[ia * DQ + ib];
+        a[r].re += ((ia == ib ? 1.0 : 0.0) - t.re) / DQ;
+        a[r].im += (0.0 - t.im) / DQ;
+      }
+    }
+    __syncthreads();
+  }
+
+  // Dykstra alternation (process.py:237-257); x = this thread's elements; returns the iteration count.
+  // p, q, y -- and x across the CP step -- live in `ws` (kWsComplex complex numbers of global memory per process,
+  // element r of thread t at [r * NT + t]: coalesced, L2-resident, touched a few times per iteration) so that the CP
+  // step -- four accumulator tiles, the iterate and its Hermitian part per thread -- has the 128 registers of a
+  // 1024-thread workgroup to itself.
+  static constexpr int kWsComplex = 5 * 4 * NT;  // p, q, y, x, and the clip's parked input
+  __device__ static int dykstra(cd (&x)[4], int n_iter, double tol, const Map& m, double* sm, cd* ws) {
+    cd* pw = ws + threadIdx.x;
+    cd* qw = pw + 4 * NT;
+    cd* yw = qw + 4 * NT;
+    cd* xw = yw + 4 * NT;
+    int it = 0;
+    for (; it < n_iter; ++it) {
+      const bool first = it == 0;  // p = q = y = 0 without reading the workspace
+      cd t[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const cd p = first ? cd{0.0, 0.0} : pw[r * NT];
+        t[r] = cd{x[r].re + p.re, x[r].im + p.im};
+      }
+      tp_project(t, m, sm);
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cd y = first ? cd{0.0, 0.0} : yw[r * NT];
+        const cd q = first ? cd{0.0, 0.0} : qw[r * NT];
+        const cd yd{t[r].re - y.re, t[r].im - y.im};
+        y.re += yd.re;
+        y.im += yd.im;
+        yw[r * NT] = y;
+        s0 += yd.re * q.re + yd.im * q.im;  // sum conj(y_diff) q
+        s1 += yd.re * q.im - yd.im * q.re;
+        t[r] = cd{y.re + q.re, y.im + q.im};
+        xw[r * NT] = x[r];
+      }
+      cp_project(t, 1e-12, m, sm, ws + 16 * NT);
+      double six[6] = {s0, s1, 0.0, 0.0, 0.0, 0.0};
+      asm volatile("" : "+v"(xw) : : "memory");  // x is really reloaded (see clip)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[r] = xw[r * NT];
+        cd p = first ? cd{0.0, 0.0} : pw[r * NT];
+        cd q = first ? cd{0.0, 0.0} : qw[r * NT];
+        const cd y = yw[r * NT];
+        const cd xd{t[r].re - x[r].re, t[r].im - x[r].im};
+        x[r].re += xd.re;
+        x[r].im += xd.im;
+        const cd pd{x[r].re - y.re, x[r].im - y.im}, qd{y.re - x[r].re, y.im - x[r].im};
+        six[2] += xd.re * p.re + xd.im * p.im;  // sum conj(x_diff) p
+        six[3] += xd.re * p.im - xd.im * p.re;
+        six[4] += pd.re * pd.re + pd.im * pd.im;
+        six[5] += qd.re * qd.re + qd.im * qd.im;
+        p.re += pd.re;
+        p.im += pd.im;
+        q.re += qd.re;
+        q.im += qd.im;
+        pw[r * NT] = p;
+        qw[r * NT] = q;
+      }
+      block_sums<NT, 6>(six, sm + oRed6);
+      const double crit = 2.0 * (hypot(six[0], six[1]) + hypot(six[2], six[3])) + six[4] + six[5];
+      __syncthreads();  // the reduction scratch is read; the next round may write it
+      if (crit < tol) {
+        ++it;
+        break;
+      }
+    }
+    return it;
+  }
+};
+
+// mode 0: Dykstra CPTP, 1: TP only, 2: CP only  (process.py:231-278); in / out [B][64][64] complex, row-major
+__global__ void __launch_bounds__(Proc64::NT) k_cptp_project64(const double* __restrict__ in, int B, int mode, int n_iter,
+                                                                double tol, double* __restrict__ out,
+                                                                int32_t* __restrict__ iters, int32_t* __restrict__ status,
+                                                                double* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) double sm64[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const Proc64::Map m;
+  const cd* src = reinterpret_cast<const cd*>(in) + (size_t)b * Proc64::DC * Proc64::DC;
+  cd x[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) x[r] = src[m.i(r) * Proc64::DC + m.j];
+  int it = 0;
+  if (mode == 0) it = Proc64::dykstra(x, n_iter, tol, m, sm64, reinterpret_cast<cd*>(ws) + (size_t)b * Proc64::kWsComplex);
+  else if (mode == 1) Proc64::tp_project(x, m, sm64);
+  else Proc64::cp_project(x, 1e-12, m, sm64, reinterpret_cast<cd*>(ws) + (size_t)b * Proc64::kWsComplex + 16 * Proc64::NT);
+  cd* dst = reinterpret_cast<cd*>(out) + (size_t)b * Proc64::DC * Proc64::DC;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dst[m.i(r) * Proc64::DC + m.j] = x[r];
+  if (threadIdx.x == 0) {
+    if (iters) iters[b] = it;
+    if (status) status[b] = (x[0].re == x[0].re) ? 0 : 4;
+  }
+}
+
+// Second half of the factored linear inversion: X = V_S^+ . T_b (64 x 64 complex each), then
+// Choi[(a d + b)][(c d + e)] = X[(a d + c)][(e d + b)].  T = F . V_P^+^T comes from k_gemm over the whole batch:
+// T[b][s][beta] complex, beta = e d + b the index of E_m[e][b] in `emats`.  One 256-thread workgroup per process;
+// T_b is staged in LDS, a thread owns one row alpha of X and 16 of its columns.
+__global__ void __launch_bounds__(256) k_lifp_kron_finish(const double* __restrict__ T, const double* __restrict__ vs_pinv,
+                                                          int B, double* __restrict__ choi, int32_t* __restrict__ status,
+                                                          int32_t* __restrict__ iters) {
+  constexpr int DC = 64, d = 8;
+  __shared__ cd tb[DC * DC];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const cd* t = reinterpret_cast<const cd*>(T) + (size_t)b * DC * DC;
+  for (int k = threadIdx.x; k < DC * DC; k += 256) tb[k] = t[k];
+  __syncthreads();
+  const int alpha = threadIdx.x >> 2, b0 = (threadIdx.x & 3) * 16;
+  const cd* vrow = reinterpret_cast<const cd*>(vs_pinv) + (size_t)alpha * DC;
+  cd acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = cd{0.0, 0.0};
+  for (int s = 0; s < DC; ++s) {
+    const cd v = vrow[s];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const cd w = tb[s * DC + b0 + k];
+      acc[k].re += v.re * w.re - v.im * w.im;
+      acc[k].im += v.re * w.im + v.im * w.re;
+    }
+  }
+  const int a = alpha / d, c = alpha % d;
+  cd* out = reinterpret_cast<cd*>(choi) + (size_t)b * DC * DC;
+  bool nan = false;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int beta = b0 + k, e = beta / d, bb = beta % d;
+    out[(a * d + bb) * DC + (c * d + e)] = acc[k];
+    nan = nan || !(acc[k].re == acc[k].re);
+  }
+  if (status) {  // an input state without counts makes its frequencies NaN (process.py:285 divides by the sum)
+    const bool any = __syncthreads_or(nan);
+    if (threadIdx.x == 0) status[b] = any ? 4 : 0;
+  }
+  if (iters && threadIdx.x == 0) iters[b] = 0;
+}
+
+}  // namespace qt

@@ -16,6 +16,7 @@
 #include "qt_large.h"
 #include "qt_ops.h"
 #include "qt_process.h"
+#include "qt_process64.h"
 #include "qt_sampler.h"
 #include "qt_small.h"
 
@@ -83,7 +84,7 @@ struct qt_handle {
   DevBuf pr_T, pr_P1, pr_P1T, pr_wrow, pr_rmap, pr_rinv, pr_fwd, pr_bwd, pr_aug;
   qt::ProductView prod{};
   // staging for host-pointer calls
-  DevBuf in0, in1, out0, out1, out2, out3, out4, proc_aug;
+  DevBuf in0, in1, out0, out1, out2, out3, out4, proc_aug, proc_ws;
   // MLE hand-off between k_mle_start and k_mle_bfgs
   DevBuf ws_x, ws_g, ws_f, ws_act;
   // BFGS (s, y) history of the n >= 4 kernels (max_iter x 2 D doubles per trial of a chunk)
@@ -307,6 +308,21 @@ void launch_transpose(qt_handle_t* h, const double* in, int R, int C, double* ou
   hipLaunchKernelGGL(qt::k_transpose_tiled<W>, dim3((C + TS - 1) / TS, (R + TS - 1) / TS), dim3(256), 0, h->stream, in, R, C, out);
 }
 
+// out[cols][rows] = inv(A^T A) A^T of the complex A[rows][cols] (plain transposes, routines.py:69-71); all device
+// pointers, enqueued on the handle's stream; the pivot report lands in h->info (0 = regular).
+int enqueue_left_inverse_complex(qt_handle_t* h, const double* dA, int rows, int cols, double* dout) {
+  DevBuf& aug = h->proc_aug;
+  HIPCHK(aug.ensure((size_t)cols * 2 * cols * 2 * sizeof(double)));
+  HIPCHK(h->info.ensure(sizeof(int)));
+  double* g = aug.as<double>();
+  dim3 gg((cols + 15) / 16, (cols + 15) / 16), gp((rows + 15) / 16, (cols + 15) / 16);
+  hipLaunchKernelGGL(qt::k_gemm<1>, gg, dim3(64), 0, h->stream, cols, cols, rows, dA, cols, 1, dA, cols, 0, g, 2 * cols);
+  launch_gauss_jordan<1>(h, cols, g, h->info.as<int>());
+  hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(64), 0, h->stream, cols, rows, cols, g + (size_t)cols * 2, 2 * cols, 0, dA, cols,
+                     1, dout, rows);
+  return 0;
+}
+
 int need_povm(qt_handle_t* h) {
   if (!h->povm_set) return fail(QT_ERR_STATE, "qt_set_povm has not been called on this handle");
   return 0;
@@ -371,7 +387,7 @@ void qt_destroy(qt_handle_t* h) {
   for (DevBuf* b : {&h->pr_T, &h->pr_P1, &h->pr_P1T, &h->pr_wrow, &h->pr_rmap, &h->pr_rinv, &h->pr_fwd, &h->pr_bwd, &h->pr_aug})
     b->release();
   for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->kron_dig, &h->in0, &h->in1,
-                    &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug, &h->ws_x, &h->ws_g, &h->ws_f,
+                    &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug, &h->proc_ws, &h->ws_x, &h->ws_g, &h->ws_f,
                     &h->ws_act, &h->hess, &h->sort_alt, &h->sort_tmp})
     b->release();
   h->proc.release();
@@ -1164,13 +1180,38 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
   QT_ENTER(h);
   if (int r = need_povm(h)) return r;
   if (!in_states) return fail(QT_ERR_ARG, "null in_states");
-  if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "process tomography supports n_qubits 1..2 in this release");
+  if (h->nq > 3) return fail(QT_ERR_UNSUPPORTED, "process tomography supports n_qubits 1..3 in this release");
   h->proc_set = false;
   if (int r = ensure_dense(h)) return r;
   const int d = h->d, D = h->D, M = h->M;
   const size_t C2 = (size_t)D * D, R = (size_t)D * M;
   qt::ProcessState& ps = h->proc;
   ps.release();
+  if (h->nq == 3) {
+    // Kronecker-factored design matrix (qt_process64.h): L = (V_S (x) V_P) Pi^T, L^+ = Pi (V_S^+ (x) V_P^+)
+    HIPCHK(hipMalloc(&ps.in_states, (size_t)D * D * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&ps.emats, (size_t)M * D * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&ps.vs_pinv, (size_t)D * D * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&ps.vp_pinv, (size_t)D * M * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&ps.vp_pinvT, (size_t)M * D * 2 * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ps.in_states, in_states, (size_t)D * D * 2 * sizeof(double),
+                          (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(qt::k_mat_from_bloch, dim3(grid_for((size_t)M * D)), dim3(256), 0, h->stream, h->nq, h->Aw.as<double>(),
+                       M, (double*)ps.emats);
+    int info[2] = {0, 0};
+    if (int r = enqueue_left_inverse_complex(h, (const double*)ps.in_states, D, D, (double*)ps.vs_pinv)) return r;
+    HIPCHK(hipMemcpyAsync(&info[0], h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (int r = enqueue_left_inverse_complex(h, (const double*)ps.emats, M, D, (double*)ps.vp_pinv)) return r;
+    HIPCHK(hipMemcpyAsync(&info[1], h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    launch_transpose<2>(h, (const double*)ps.vp_pinv, D, M, (double*)ps.vp_pinvT);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (info[0] != 0) return fail(QT_ERR_SINGULAR, "input states do not span the operator space (column %d)", info[0] - 1);
+    if (info[1] != 0) return fail(QT_ERR_SINGULAR, "POVM is not informationally complete (column %d)", info[1] - 1);
+    ps.factored = true;
+    h->proc_set = true;
+    return 0;
+  }
   HIPCHK(hipMalloc(&ps.in_states, (size_t)D * D * 2 * sizeof(double)));
   HIPCHK(hipMalloc(&ps.emats, (size_t)M * D * 2 * sizeof(double)));
   HIPCHK(hipMalloc(&ps.lifp, R * C2 * 2 * sizeof(double)));
@@ -1205,10 +1246,23 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
 int qt_process_get_operators(qt_handle_t* h, double* lifp_oper, double* lifp_oper_inv, int flags) {
   QT_ENTER(h);
   if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
+  if (h->proc.factored)
+    return fail(QT_ERR_UNSUPPORTED, "at n = 3 the design matrix is kept Kronecker-factored (qt_process_get_factors); its dense "
+                                    "form would be 2 x 906 MB");
   const size_t bytes = (size_t)h->D * h->M * h->D * h->D * 2 * sizeof(double);
   const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   if (lifp_oper) HIPCHK(hipMemcpyAsync(lifp_oper, h->proc.lifp, bytes, kind, h->stream));
   if (lifp_oper_inv) HIPCHK(hipMemcpyAsync(lifp_oper_inv, h->proc.pinv, bytes, kind, h->stream));
+  return finish(h, flags);
+}
+
+int qt_process_get_factors(qt_handle_t* h, double* vs_pinv, double* vp_pinv, int flags) {
+  QT_ENTER(h);
+  if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
+  if (!h->proc.factored) return fail(QT_ERR_UNSUPPORTED, "the design matrix is dense for n <= 2 (qt_process_get_operators)");
+  const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (vs_pinv) HIPCHK(hipMemcpyAsync(vs_pinv, h->proc.vs_pinv, (size_t)h->D * h->D * 2 * sizeof(double), kind, h->stream));
+  if (vp_pinv) HIPCHK(hipMemcpyAsync(vp_pinv, h->proc.vp_pinv, (size_t)h->D * h->M * 2 * sizeof(double), kind, h->stream));
   return finish(h, flags);
 }
 
@@ -1226,6 +1280,34 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
   if (int r = stage_out(h, h->out0, choi, (size_t)B * D * D * 2, flags, &dchoi)) return r;
   if (int r = stage_out(h, h->out1, iters, (size_t)B, flags, &dit)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
+  if (h->proc.factored) {  // n = 3: X = V_S^+ F V_P^+^T, two small products per process (qt_process64.h)
+    if ((size_t)B * D > (size_t)1 << 26) return fail(QT_ERR_ARG, "batch too large");
+    const int R = D * M;  // 13824: a multiple of 64, the pitch k_lifp_freq pads to
+    HIPCHK(h->ws_x.ensure(((size_t)B * R + 192) * sizeof(double)));
+    HIPCHK(h->ws_g.ensure((size_t)B * D * D * 2 * sizeof(double)));
+    double *F = h->ws_x.as<double>(), *T = h->ws_g.as<double>(), *raw = dchoi;
+    if (cptp) {
+      HIPCHK(h->ws_f.ensure((size_t)B * D * D * 2 * sizeof(double)));
+      raw = h->ws_f.as<double>();
+    }
+    hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 15) / 16), dim3(256), 0, h->stream, dc, B * D, M, D, R, F);
+    // T[(b, s)][beta] = sum_m F[(b, s)][m] V_P^+[beta][m]: real x complex = a real GEMM with 2 D interleaved columns
+    hipLaunchKernelGGL(qt::k_gemm<0>, dim3(2 * D / 16, (B * D + 15) / 16), dim3(64), 0, h->stream, B * D, 2 * D, M, F, M, 0,
+                       (const double*)h->proc.vp_pinvT, 2 * D, 0, T, 2 * D);
+    hipLaunchKernelGGL(qt::k_lifp_kron_finish, dim3(B), dim3(256), 0, h->stream, (const double*)T, (const double*)h->proc.vs_pinv,
+                       B, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
+    if (cptp) {
+      if (int r = allow_big_lds(qt::k_cptp_project64, qt::Proc64::kLdsBytes)) return r;
+      HIPCHK(h->proc_ws.ensure((size_t)B * qt::Proc64::kWsComplex * 2 * sizeof(double)));  // Dykstra's p, q, y, x + the clip's input
+      hipLaunchKernelGGL(qt::k_cptp_project64, dim3(B), dim3(qt::Proc64::NT), qt::Proc64::kLdsBytes, h->stream, (const double*)raw,
+                         B, 0, 1000, 1e-12, dchoi, dit, dst, h->proc_ws.as<double>());
+    }
+    if (int r = fetch_out(h, dchoi, choi, (size_t)B * D * D * 2, flags)) return r;
+    if (int r = fetch_out(h, dit, iters, (size_t)B, flags)) return r;
+    if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
+    if (int r = finish(h, flags)) return r;
+    return count_bad(status, B, flags);
+  }
   const size_t dyn = (size_t)D * M * sizeof(double);
   if (dyn > 32 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the process kernel");
   const int R = D * M, Rp = (R + 63) / 64 * 64;
@@ -1281,6 +1363,7 @@ int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, doub
   if (B < 0 || (B > 0 && (!counts || !choi))) return fail(QT_ERR_ARG, "bad pgdb_batch arguments");
   if (stop_rule != 0 && stop_rule != 1) return fail(QT_ERR_ARG, "stop_rule must be 0 (reference) or 1 (converged)");
   if (n_iter < 0) return fail(QT_ERR_ARG, "n_iter must be >= 0");
+  if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "'pgdb' supports n_qubits 1..2 in this release ('lifp' and 'states': 1..3)");
   if (B == 0) return 0;
   const int D = h->D, M = h->M;
   const int64_t* dc;
@@ -1311,6 +1394,7 @@ int qt_mhmc_process(qt_handle_t* h, const int64_t* counts, int C, const double* 
   if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
   if (C < 0 || T < 0 || (C > 0 && T > 0 && (!counts || !choi_init || !deltas || !uniforms || !chain || !accepted)))
     return fail(QT_ERR_ARG, "bad mhmc_process arguments");
+  if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "the process chain supports n_qubits 1..2 in this release");
   if (C == 0 || T == 0) return 0;
   const int D = h->D, M = h->M;
   const size_t ne = (size_t)D * D;
@@ -1342,7 +1426,7 @@ int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode
   QT_ENTER(h);
   if (B < 0 || (B > 0 && (!choi_in || !choi_out))) return fail(QT_ERR_ARG, "bad cptp_project arguments");
   if (mode < 0 || mode > 2) return fail(QT_ERR_ARG, "mode must be 0 (CPTP), 1 (TP) or 2 (CP)");
-  if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "process tomography supports n_qubits 1..2 in this release");
+  if (h->nq > 3) return fail(QT_ERR_UNSUPPORTED, "process tomography supports n_qubits 1..3 in this release");
   if (B == 0) return 0;
   const int D = h->D;
   const double* din;
@@ -1351,7 +1435,12 @@ int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode
   if (int r = stage_in(h, h->in0, choi_in, (size_t)B * D * D * 2, flags, &din)) return r;
   if (int r = stage_out(h, h->out0, choi_out, (size_t)B * D * D * 2, flags, &dout)) return r;
   if (int r = stage_out(h, h->out1, iters, (size_t)B, flags, &dit)) return r;
-  if (D == 4)
+  if (D == 64) {
+    if (int r = allow_big_lds(qt::k_cptp_project64, qt::Proc64::kLdsBytes)) return r;
+    if (mode != 1) HIPCHK(h->proc_ws.ensure((size_t)B * qt::Proc64::kWsComplex * 2 * sizeof(double)));  // Dykstra's p, q, y, x + the clip's input
+    hipLaunchKernelGGL(qt::k_cptp_project64, dim3(B), dim3(qt::Proc64::NT), qt::Proc64::kLdsBytes, h->stream, din, B, mode, n_iter,
+                       tol, dout, dit, (int32_t*)nullptr, h->proc_ws.as<double>());
+  } else if (D == 4)
     hipLaunchKernelGGL(qt::k_cptp_project<4>, dim3(B), dim3(qt::ProcWG<4>::NT), 0, h->stream, din, B, mode, n_iter, tol, dout,
                        dit);
   else

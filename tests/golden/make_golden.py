@@ -426,6 +426,70 @@ def gen_process():
 
 
 # --------------------------------------------------------------------------------------
+# a11-a15 at n = 3 (process.py:142-229 is size-generic; 13824 x 4096 complex design matrix, minutes in the reference)
+# --------------------------------------------------------------------------------------
+def gen_process3():
+    import scipy.linalg as la
+    import time as _time
+    from quantpy.routines import _mat2vec, _vec2mat
+
+    def dyk_iters(tmg_, choi_vec):
+        x = choi_vec.copy()
+        p = q = y = 0
+        for i in range(1000):
+            y_diff = tmg_.tp_projection(qp.Channel(_vec2mat(x + p)), vectorized=True) - y
+            y = y + y_diff
+            x_diff = tmg_.cp_projection(qp.Channel(_vec2mat(y + q)), vectorized=True) - x
+            x = x + x_diff
+            crit = 2 * (np.abs(np.sum(y_diff.T.conj() * q)) + np.abs(np.sum(x_diff.T.conj() * p)))
+            p_diff = x - y
+            p = p + p_diff
+            q_diff = y - x
+            q = q + q_diff
+            crit += la.norm(p_diff) ** 2 + la.norm(q_diff) ** 2
+            if crit < 1e-12:
+                break
+        return i + 1
+
+    out = {}
+    t0 = _time.time()
+    np.random.seed(31)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 3))
+    tmg.experiment(10000, "proj-set")
+    out["Q0_seed"], out["Q0_shots"] = np.array(31), np.array(10000)
+    out["Q_true_choi"] = tmg.channel.choi.matrix
+    out["Q_input_states"] = np.stack([s_.matrix for s_ in tmg.input_basis.elements])
+    out["Q0_counts"] = tmg.results
+    ch = tmg.point_estimate("lifp", cptp=False)  # builds _lifp_oper (13824 x 4096) and its left inverse
+    print(f"   design matrix + left inverse + lifp: {_time.time() - t0:.0f} s")
+    out["Q_lifp_oper_rows"] = tmg._lifp_oper[::997]
+    out["Q_lifp_oper_inv_cols"] = tmg._lifp_oper_inv[:, ::1999]
+    out["Q_lifp_oper_abs_sum"] = np.array(np.abs(tmg._lifp_oper).sum())
+    # a second data set on the same operators (fewer shots would change the operator only through the
+    # shots ratio N_s / sum N, which is the same): the estimators below reuse tmg._lifp_oper_inv, as
+    # point_estimate() itself would recompute it identically
+    for key, counts in (("Q0", tmg.results), ("Q1", None)):
+        if counts is None:
+            np.random.seed(32)
+            tmg.experiment(10000, "proj-set")
+            out["Q1_seed"], out["Q1_shots"] = np.array(32), np.array(10000)
+            out["Q1_counts"] = tmg.results
+        # (copies: _vec2mat hands back a transposed view, _mat2vec of that is again a view, and _cptp_projection_vec
+        #  updates its argument in place -- cptp_projection(ch) would overwrite ch's own matrix)
+        raw = tmg._point_estimate_lifp(cptp=False).choi.matrix.copy()
+        out[key + "_choi_nocptp"] = raw
+        out[key + "_dykstra_iters"] = np.array(dyk_iters(tmg, _mat2vec(raw.copy())))
+        out[key + "_choi_cptp"] = tmg.cptp_projection(qp.Channel(raw.copy())).choi.matrix.copy()
+        out[key + "_tp_only"] = tmg.tp_projection(qp.Channel(raw.copy())).choi.matrix.copy()
+        out[key + "_cp_only"] = tmg.cp_projection(qp.Channel(raw.copy())).choi.matrix.copy()
+        assert np.abs(raw - out[key + "_choi_cptp"]).max() > 1e-6
+        out[key + "_states_lin"] = tmg._point_estimate_states(False, "lin", True, "lin", 1000, 1e-10).choi.matrix
+        out[key + "_states_lin_cptp"] = tmg._point_estimate_states(True, "lin", True, "lin", 1000, 1e-10).choi.matrix
+        print(f"   {key}: dykstra iters={int(out[key + '_dykstra_iters'])}  ({_time.time() - t0:.0f} s)")
+    save("process3", **out)
+
+
+# --------------------------------------------------------------------------------------
 # (f) MomentInterval: closed-form CI of the CLI scripts  (interval.py:59-110, stats.py)
 # --------------------------------------------------------------------------------------
 def gen_moment():
@@ -827,7 +891,7 @@ def gen_leftovers():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large",
-                             "pgdb", "constr", "mhmc", "holder", "leftovers"]
+                             "pgdb", "constr", "mhmc", "holder", "leftovers", "process3"]
     table = {
         "operators": gen_operators,
         "states": gen_states_and_born,
@@ -835,6 +899,7 @@ if __name__ == "__main__":
         "chol": gen_chol_nll,
         "mle": gen_mle,
         "process": gen_process,
+        "process3": gen_process3,
         "moment": gen_moment,
         "bootstrap": gen_bootstrap,
         "large": gen_large,

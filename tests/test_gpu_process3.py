@@ -1,0 +1,96 @@
+"""GPU: process tomography of THREE qubits (64 input states x 216 POVM rows, 64 x 64 Choi matrix) against fixtures the
+reference itself produced (tests/golden/process3.npz, make_golden.py:gen_process3 -- there the 13824 x 4096 complex
+design matrix and its left inverse are built densely; here the design matrix stays Kronecker-factored,
+csrc/qt_process64.h)."""
+import numpy as np
+import pytest
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g3():
+    return load_golden("process3")
+
+
+def _tomograph(qp, g, key):
+    np.random.seed(int(g[key + "_seed"]))
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 3))
+    tmg.experiment(int(g[key + "_shots"]), "proj-set")
+    return tmg
+
+
+def test_n3_experiment_is_bit_exact(g3):
+    import quantpy_amd as qp
+
+    tmg = _tomograph(qp, g3, "Q0")
+    assert np.abs(tmg.channel.choi.matrix - g3["Q_true_choi"]).max() < 1e-14
+    assert np.abs(np.stack([s.matrix for s in tmg.input_basis.elements]) - g3["Q_input_states"]).max() < 1e-15
+    assert np.array_equal(tmg.results, g3["Q0_counts"])  # 64 x 27 multinomials on the reference's stream
+
+
+def test_n3_factored_left_inverse_is_the_references(g3):
+    """Sampled columns of the reference's 4096 x 13824 `_lifp_oper_inv` against the Kronecker product of the two
+    factor inverses (include/qtomo.h: qt_process_get_factors), and sampled rows of `_lifp_oper` against the factors
+    themselves."""
+    import quantpy_amd as qp
+    from quantpy_amd import _capi
+
+    tmg = _tomograph(qp, g3, "Q0")
+    eng = tmg._engine()
+    d, D, M = 8, 64, 216
+    vs = np.empty((D, D), dtype=np.complex128)
+    vp = np.empty((D, M), dtype=np.complex128)
+    assert eng.lib.qt_process_get_factors(eng._h, vs.ctypes.data, vp.ctypes.data, _capi.QT_HOST_PTR) == 0
+    cols = np.arange(0, D * M, 1999)
+    want = g3["Q_lifp_oper_inv_cols"]  # [4096][len(cols)], row index v = col * D + row of the Choi matrix
+    a, b, c, e = np.meshgrid(np.arange(d), np.arange(d), np.arange(d), np.arange(d), indexing="ij")
+    v = (c * d + e) * D + (a * d + b)
+    got = np.empty_like(want)
+    for k, col in enumerate(cols):
+        s, m = divmod(int(col), M)
+        got[v.ravel(), k] = (vs[(a * d + c).ravel(), s] * vp[(e * d + b).ravel(), m])
+    assert np.abs(got - want).max() < 1e-9 * np.abs(want).max()
+    with pytest.raises(RuntimeError):
+        eng.process_operators()  # the dense form is not materialised at n = 3
+
+
+@pytest.mark.parametrize("key", ["Q0", "Q1"])
+def test_n3_lifp_and_projections_match_the_reference(g3, key):
+    import quantpy_amd as qp
+
+    tmg = _tomograph(qp, g3, key)
+    assert np.array_equal(tmg.results, g3[key + "_counts"])
+    raw = tmg.point_estimate("lifp", cptp=False)
+    assert np.abs(raw.choi.matrix - g3[key + "_choi_nocptp"]).max() < 1e-10
+    fixed = tmg.point_estimate("lifp", cptp=True)
+    assert tmg.cptp_iterations == int(g3[key + "_dykstra_iters"])
+    assert np.abs(fixed.choi.matrix - g3[key + "_choi_cptp"]).max() < 1e-9
+    assert fixed.is_cptp(verbose=False)
+    ref_raw = qp.Channel(g3[key + "_choi_nocptp"])
+    assert np.abs(tmg.tp_projection(ref_raw).choi.matrix - g3[key + "_tp_only"]).max() < 1e-12
+    assert np.abs(tmg.cp_projection(ref_raw).choi.matrix - g3[key + "_cp_only"]).max() < 1e-11
+    assert np.abs(tmg.cptp_projection(ref_raw).choi.matrix - g3[key + "_choi_cptp"]).max() < 1e-9
+
+
+def test_n3_states_estimator_and_batch(g3):
+    import quantpy_amd as qp
+
+    tmg = _tomograph(qp, g3, "Q0")
+    st = tmg.point_estimate("states", cptp=False)
+    assert np.abs(st.choi.matrix - g3["Q0_states_lin"]).max() < 1e-9
+    st = tmg.point_estimate("states", cptp=True)
+    assert np.abs(st.choi.matrix - g3["Q0_states_lin_cptp"]).max() < 1e-8
+    # a batch: every process is reconstructed independently of its neighbours
+    counts = np.stack([g3["Q0_counts"], g3["Q1_counts"], g3["Q0_counts"]])
+    eng = tmg._engine()
+    choi, iters = eng.lifp(counts, cptp=True, return_iters=True)
+    assert list(iters) == [int(g3["Q0_dykstra_iters"]), int(g3["Q1_dykstra_iters"]), int(g3["Q0_dykstra_iters"])]
+    assert np.array_equal(choi[0], choi[2])
+    assert np.abs(choi[1] - g3["Q1_choi_cptp"]).max() < 1e-9
+    # a positive-definite Choi matrix is left alone by the CP step (Cholesky short cut), a clipped one is PSD
+    assert np.abs(eng.cptp_project(g3["Q_true_choi"] + 1e-3 * np.eye(64), mode="cp") - (g3["Q_true_choi"] + 1e-3 * np.eye(64))).max() < 1e-15
+    assert np.linalg.eigvalsh(eng.cptp_project(g3["Q0_choi_nocptp"], mode="cp")).min() > 0
+    with pytest.raises(RuntimeError):
+        tmg.point_estimate("pgdb")

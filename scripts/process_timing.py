@@ -13,14 +13,17 @@ import torch  # noqa: E402
 import quantpy_amd as qp  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+NQ = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # 3: 64 x 216 rows, Kronecker-factored set-up (qt_process64.h)
+DC = 4**NQ
 np.random.seed(11)
-tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 2))
+tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, NQ))
 tmg.experiment(10000, "proj-set")
 t0 = time.perf_counter()
 eng = tmg._engine()
 eng.sync()
 t1 = time.perf_counter()
-print(f"process set-up (qt_set_povm + qt_process_setup, 576 x 256 complex design matrix): {1e3 * (t1 - t0):.2f} ms", flush=True)
+print(f"n = {NQ} process set-up (qt_set_povm + qt_process_setup, {DC * tmg.tomographs[0].results.size} x {DC * DC} complex design matrix"
+      f"{', kept as two Kronecker factors' if NQ == 3 else ''}): {1e3 * (t1 - t0):.2f} ms", flush=True)
 boot = qp.ProcessTomograph(tmg.point_estimate("lifp"))
 few = []
 for _ in range(8):
@@ -28,7 +31,7 @@ for _ in range(8):
     few.append(boot.results)
 counts = np.concatenate([np.stack(few)] * (B // 8))
 cd = torch.from_numpy(np.ascontiguousarray(counts)).cuda()
-choi = torch.empty((B, 16, 16), dtype=torch.complex128, device="cuda")
+choi = torch.empty((B, DC, DC), dtype=torch.complex128, device="cuda")
 it = torch.zeros(B, dtype=torch.int32, device="cuda")
 for cptp in (False, True):
     eng.lifp_dev(cd, choi, cptp=cptp, iters=it)

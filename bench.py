@@ -438,6 +438,23 @@ def main():
             others["configs[2] lifp" + (" + CPTP projection" if cptp else "")] = {
                 "batch": pb, "ms_per_launch": round(ms, 4), "value": round(pb / ms * 1e3, 1), "unit": "Choi reconstructions/s"}
         del pc, pout
+        # the same at n = 3 (not a BASELINE config; 64 x 216 rows, Kronecker-factored set-up, 64 x 64 CPTP projection)
+        np.random.seed(31)
+        ptm3 = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 3))
+        ptm3.experiment(10000, "proj-set")
+        t3 = time.perf_counter()
+        peng3 = ptm3._engine()
+        peng3.sync()
+        setup3_ms = (time.perf_counter() - t3) * 1e3
+        pb3 = 64
+        pc3 = torch.from_numpy(np.ascontiguousarray(np.stack([ptm3.results] * pb3))).cuda()
+        pout3 = torch.empty((pb3, 64, 64), dtype=torch.complex128, device="cuda")
+        for cptp in (False, True):
+            ms = timed(lambda: peng3.lifp_dev(pc3, pout3, cptp=cptp), 3, peng3)
+            others["n=3 process lifp" + (" + CPTP projection" if cptp else "")] = {
+                "batch": pb3, "ms_per_launch": round(ms, 4), "value": round(pb3 / ms * 1e3, 1), "unit": "Choi reconstructions/s",
+                "setup_ms": round(setup3_ms, 3)}
+        del pc3, pout3
         # host-pointer API (NumPy in, NumPy out): H2D of the counts + kernel + D2H of rho + synchronise, MEASURED
         reps = 50
         eng.mle(counts)

@@ -157,6 +157,8 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
 /* ---- a16: quantpy/geometry.py:5-20 hs_dst --------------------------------------------------- */
 /* dist[b] = sqrt(|Tr((rho_b - centre)^2)|) / sqrt(2), set to 0 below 1e-15 */
 int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, int B, double* dist, int flags);
+/* the same for dim x dim matrices whatever the handle's n_qubits (Choi matrices of an n-qubit channel: dim = 4^n) */
+int qt_hs_dist_dim(qt_handle_t* h, int dim, const double* rho, const double* centre, int B, double* dist, int flags);
 
 /* ---- a16: quantpy/tomography/interval.py:610-612 (and :683-685) -------------------------------- */
 /* `dist.sort()`: ascending in-place sort of n float64 values (radix sort on the device; NaN last). */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "qt_mle_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, _vp, _vp, _vp, _vp, _c_int]),
     "qt_mhmc_state": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _c_int]),
     "qt_hs_dist_batch": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int]),
+    "qt_hs_dist_dim": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, _vp, _c_int]),
     "qt_sort_f64": (_c_int, [_vp, _vp, ctypes.c_longlong, _c_int]),
     "qt_sorted_quantiles": (_c_int, [_vp, _vp, ctypes.c_longlong, _vp, _c_int, _vp, _c_int]),
     "qt_legacy_multinomial": (_c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp]),

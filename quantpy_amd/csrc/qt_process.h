@@ -5,7 +5,7 @@
 //   CPTP projection  Dykstra alternation of the TP and CP projections      process.py:231-278
 //
 // One workgroup reconstructs one process: thread (r, c) owns element C[r][c] of the DC x DC Choi
-// matrix (DC = 4^n: 4 or 16) through the whole Dykstra loop; the TP step is a partial-trace
+// matrix (DC = 4^n: 4 or 16; DC = 64 has its own layout, qt_process64.h) through the whole Dykstra loop; the TP step is a partial-trace
 // reduction in LDS, the CP step a parallel-order Jacobi eigensolver in LDS.
 #pragma once
 #include <hip/hip_runtime.h>

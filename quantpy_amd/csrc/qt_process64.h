@@ -12,12 +12,12 @@
 // qt_process_setup factors the design matrix this way for n = 3; k_lifp_kron_finish is the second product + the
 // index shuffle (the first one, over the whole batch, is k_gemm).
 //
-// CPTP projection (process.py:231-278) for the 64 x 64 Choi matrix: one 1024-thread workgroup per process, FOUR
-// elements per thread -- the four a wavefront's lane receives from v_mfma_f64_16x16x4_f64 for its 16 x 16 tile
-// (wavefront w <-> tile w: rows 16 (w / 4) + kq + 4 r, column 16 (w % 4) + r16) -- so the Dykstra variables x, p, q, y
-// stay in registers through the loop and the products of the CP step's sign iteration (qt_signclip_wg.h explains
-// the iteration) leave their result where the element-wise updates want it.  LDS: two 64 x 65 complex images
-// (the third image of SignClipWG is the accumulator registers here) + a column buffer for the Cholesky test.
+// CPTP projection (process.py:231-278) for the 64 x 64 Choi matrix: one 512-thread workgroup per process, EIGHT
+// elements per thread -- those a wavefront's lane receives from v_mfma_f64_16x16x4_f64 for its two 16 x 16 tiles
+// (wavefront w <-> tiles 2w, 2w + 1: rows 16 (w / 2) + kq + 4 r, columns 32 (w % 2) + 16 t + r16) -- so the products
+// of the CP step's sign iteration (qt_signclip_wg.h explains the iteration) leave their result where the element-wise
+// updates of the Dykstra loop want it.  LDS: two 64 x 65 complex images (the third image of SignClipWG is the
+// accumulator registers here) + a column buffer for the Cholesky test; Dykstra's p, q, y wait in global memory.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,19 +28,26 @@
 namespace qt {
 
 struct Proc64 {
-  static constexpr int DC = 64, DQ = 8, NT = 1024, NW = NT / 64, P = DC + 1;
+  // 512 threads: a wavefront owns TWO neighbouring 16 x 16 tiles of the matrix (tiles 2w and 2w + 1 of the 4 x 4 grid:
+  // same rows, adjacent columns), eight elements per thread.  With 1024 threads x 4 elements the 128-register cap of
+  // a 1024-thread workgroup left the Dykstra body + the sign iteration 75-98 registers short (280-370 B of scratch);
+  // eight waves have 256 registers each, the two tiles share every A-operand read, and a wavefront carries four
+  // independent MFMA chains.  The matrix pipe sees the same 256 MFMAs per SIMD and product either way.
+  static constexpr int DC = 64, DQ = 8, NT = 512, NW = NT / 64, EPT = 8, P = DC + 1;
   // LDS layout, offsets in doubles (all even: cd accesses are 16-byte aligned)
   static constexpr int oImg0 = 0, oImg1 = oImg0 + 2 * DC * P, oCol = oImg1 + 2 * DC * P, oTp = oCol + 2 * 2 * DC,
                        oRed = oTp + 2 * DC, oRed6 = oRed + 32, kDoubles = oRed6 + 6 * NW;
   static constexpr size_t kLdsBytes = (size_t)kDoubles * sizeof(double);
+  static constexpr int kWsComplex = 5 * EPT * NT;  // global workspace per process: p, q, y, x, the clip's parked input
 
-  struct Map {  // this thread's four elements (i[r], j)
-    int row0, col0, r16, kq, j;
-    __device__ Map() {
-      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      row0 = 16 * (w >> 2), col0 = 16 * (w & 3), r16 = lane & 15, kq = lane >> 4, j = col0 + r16;
+  struct Map {  // element r of this thread: row i(r), column j(r); r = 4 * tile + accumulator slot
+    int row0, col0, r16, kq;
+    __device__ explicit Map(int tid) {
+      const int w = tid >> 6, lane = tid & 63;
+      row0 = 16 * (w >> 1), col0 = 32 * (w & 1), r16 = lane & 15, kq = lane >> 4;
     }
-    __device__ __forceinline__ int i(int r) const { return row0 + kq + 4 * r; }
+    __device__ __forceinline__ int i(int r) const { return row0 + kq + 4 * (r & 3); }
+    __device__ __forceinline__ int j(int r) const { return col0 + 16 * (r >> 2) + r16; }
   };
 
   __device__ static double wsum(double* red, double v) {  // identical bits in every thread
@@ -54,35 +61,43 @@ struct Proc64 {
     return s;
   }
 
-  // (re, im) of this wavefront's tile of A B; no barrier inside
-  __device__ __forceinline__ static void tile_product(const cd* A, const cd* B, const Map& m, sc_v4f64& cre, sc_v4f64& cim) {
-    cre = sc_v4f64{0.0, 0.0, 0.0, 0.0};
-    cim = cre;
+  // (re, im) of this wavefront's two tiles of A B (element r of the result in c[r]); no barrier inside
+  __device__ __forceinline__ static void tile_product(const cd* A, const cd* B, const Map& m, cd (&c)[EPT]) {
+    sc_v4f64 re0 = {0.0, 0.0, 0.0, 0.0}, im0 = re0, re1 = re0, im1 = re0;
     const cd* ap = A + (m.row0 + m.r16) * P + m.kq;
     const cd* bp = B + m.kq * P + m.col0 + m.r16;
 #pragma unroll 4
     for (int k0 = 0; k0 < DC; k0 += 4) {
-      const cd a = ap[k0], b = bp[k0 * P];
-      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, cre, 0, 0, 0);
-      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, cim, 0, 0, 0);
-      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, cre, 0, 0, 0);
-      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, cim, 0, 0, 0);
+      const cd a = ap[k0], b0 = bp[k0 * P], b1 = bp[k0 * P + 16];
+      re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, re0, 0, 0, 0);
+      im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.im, im0, 0, 0, 0);
+      re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.re, re1, 0, 0, 0);
+      im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.im, im1, 0, 0, 0);
+      re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b0.im, re0, 0, 0, 0);
+      im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.re, im0, 0, 0, 0);
+      re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b1.im, re1, 0, 0, 0);
+      im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b1.re, im1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      c[r] = cd{re0[r], im0[r]};
+      c[4 + r] = cd{re1[r], im1[r]};
     }
   }
 
   // Hermitian completion from the lower triangle (LAPACK zheevd, uplo = 'L': what numpy.linalg.eigh reads)
-  __device__ static void complete_lower(cd (&a)[4], const Map& m, double* sm) {
+  __device__ static void complete_lower(cd (&a)[EPT], const Map& m, double* sm) {
     cd* X = reinterpret_cast<cd*>(sm + oImg0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X[m.i(r) * P + m.j] = a[r];
+    for (int r = 0; r < EPT; ++r) X[m.i(r) * P + m.j(r)] = a[r];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = m.i(r);
-      if (i < m.j) {
-        const cd t = X[m.j * P + i];
+    for (int r = 0; r < EPT; ++r) {
+      const int i = m.i(r), j = m.j(r);
+      if (i < j) {
+        const cd t = X[j * P + i];
         a[r] = cd{t.re, -t.im};
-      } else if (i == m.j) {
+      } else if (i == j) {
         a[r].im = 0.0;
       }
     }
@@ -92,30 +107,35 @@ struct Proc64 {
   // Does the (Hermitian) matrix have a Cholesky factorisation with every pivot above eps?  Then no eigenvalue is
   // clipped by more than eps and the CP projection is the identity (the common case once Dykstra's iterates
   // settle).  Right-looking elimination on the register-resident elements; only column k travels through LDS.
-  __device__ static bool is_pd(const cd (&a)[4], double eps, const Map& m, double* sm) {
-    cd w[4] = {a[0], a[1], a[2], a[3]};
+  __device__ static bool is_pd(const cd (&a)[EPT], double eps, const Map& m, double* sm) {
+    cd w[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) w[r] = a[r];
     bool pd = true;
     for (int k = 0; k < DC; ++k) {
       cd* col = reinterpret_cast<cd*>(sm + oCol) + (k & 1) * DC;
-      if (m.j == k) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) col[m.i(r)] = w[r];
-      }
+      for (int r = 0; r < EPT; ++r)
+        if (m.j(r) == k) col[m.i(r)] = w[r];
       __syncthreads();
       const double piv = col[k].re;
       if (!(piv > eps)) {  // uniform: every thread reads the same pivot
         pd = false;
         break;
       }
-      if (m.j > k) {
-        const double inv = 1.0 / piv;
-        const cd cj = col[m.j];
+      const double inv = 1.0 / piv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (m.i(r) > k) {
-            const cd ci = col[m.i(r)];
-            w[r].re -= (ci.re * cj.re + ci.im * cj.im) * inv;  // a_ik conj(a_jk) / a_kk
-            w[r].im -= (ci.im * cj.re - ci.re * cj.im) * inv;
+      for (int t = 0; t < 2; ++t) {
+        if (m.j(4 * t) > k) {
+          const cd cj = col[m.j(4 * t)];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * t + rr;
+            if (m.i(r) > k) {
+              const cd ci = col[m.i(r)];
+              w[r].re -= (ci.re * cj.re + ci.im * cj.im) * inv;  // a_ik conj(a_jk) / a_kk
+              w[r].im -= (ci.im * cj.re - ci.re * cj.im) * inv;
+            }
           }
         }
       }
@@ -125,31 +145,31 @@ struct Proc64 {
   }
 
   // U max(lambda, eps) U^dagger of the Hermitian matrix whose elements a[] this thread holds (sign-function
-  // iteration of qt_signclip_wg.h; X in image 0, Y / W / A in image 1, products land in registers)
-  // `park` = 4 x NT complex of global memory for this process (element r of thread t at [r * NT + t]): the input
-  // waits there while the iteration runs, so that the loop's live registers are the product tiles and the iterate
-  __device__ static void clip(cd (&a)[4], double eps, const Map& m, double* sm, cd* park) {
+  // iteration of qt_signclip_wg.h; X in image 0, Y / W / A in image 1, products land in registers).
+  // `park` = EPT x NT complex of global memory for this process (element r of thread t at [r * NT + t]): the input
+  // waits there while the iteration runs.
+  __device__ static void clip(cd (&a)[EPT], double eps, const Map& m, double* sm, cd* park) {
     cd* X = reinterpret_cast<cd*>(sm + oImg0);
     cd* Y = reinterpret_cast<cd*>(sm + oImg1);
     double* red = sm + oRed;
-    int e[4], et[4];
+    int e[EPT], et[EPT];
     double n2 = 0.0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      e[r] = m.i(r) * P + m.j;
-      et[r] = m.j * P + m.i(r);
+    for (int r = 0; r < EPT; ++r) {
+      e[r] = m.i(r) * P + m.j(r);
+      et[r] = m.j(r) * P + m.i(r);
       if (e[r] == et[r]) a[r].im = 0.0;
       n2 += a[r].re * a[r].re + a[r].im * a[r].im;
     }
     const double nrm2 = wsum(red, n2);
     if (!(nrm2 > 0.0)) {  // the zero matrix (or NaN input): every eigenvalue is clipped to eps
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a[r] = cd{nrm2 == 0.0 ? (e[r] == et[r] ? eps : 0.0) : nrm2, 0.0};
+      for (int r = 0; r < EPT; ++r) a[r] = cd{nrm2 == 0.0 ? (e[r] == et[r] ? eps : 0.0) : nrm2, 0.0};
       return;
     }
     const double scale = 1.0 / sqrt(nrm2);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < EPT; ++r) {
       park[r * NT + threadIdx.x] = a[r];
       X[e[r]] = cd{a[r].re * scale, a[r].im * scale};
     }
@@ -157,17 +177,17 @@ struct Proc64 {
     bool lifting = true;
     int ns_left = 12;
     for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (wsum returns identical bits)
-      sc_v4f64 pre, pim;
-      tile_product(X, X, m, pre, pim);
+      cd pr[EPT];
+      tile_product(X, X, m, pr);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Y[e[r]] = cd{pre[r], pim[r]};  // (image 1 is idle: the last product ended behind a barrier)
+      for (int r = 0; r < EPT; ++r) Y[e[r]] = pr[r];  // (image 1 is idle: the last product ended behind a barrier)
       __syncthreads();
-      cd y[4];
+      cd y[EPT];
       double rs = 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < EPT; ++r) {
         const cd yt = Y[et[r]];
-        y[r] = cd{0.5 * (pre[r] + yt.re), 0.5 * (pim[r] - yt.im)};  // Hermitian part
+        y[r] = cd{0.5 * (pr[r].re + yt.re), 0.5 * (pr[r].im - yt.im)};  // Hermitian part
         const double dr = (e[r] == et[r] ? 1.0 : 0.0) - y[r].re;
         rs += dr * dr + y[r].im * y[r].im;
       }
@@ -176,38 +196,38 @@ struct Proc64 {
       const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);
       const double alpha = lifting ? 2.0 : 1.5, beta = lifting ? -1.0 : -0.5;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Y[e[r]] = cd{fma(beta, y[r].re, e[r] == et[r] ? alpha : 0.0), beta * y[r].im};  // W
+      for (int r = 0; r < EPT; ++r) Y[e[r]] = cd{fma(beta, y[r].re, e[r] == et[r] ? alpha : 0.0), beta * y[r].im};  // W
       __syncthreads();
-      tile_product(X, Y, m, pre, pim);
+      tile_product(X, Y, m, pr);
       __syncthreads();  // every wavefront has read X and W
 #pragma unroll
-      for (int r = 0; r < 4; ++r) X[e[r]] = cd{pre[r], pim[r]};
+      for (int r = 0; r < EPT; ++r) X[e[r]] = pr[r];
       __syncthreads();
       if (last || !(res == res)) break;
     }
     // S = sign(A) sits in X.  R = (A + A S) / 2 + eps (I - S) / 2
-    cd s[4];
+    cd s[EPT];
     asm volatile("" : "+v"(park) : : "memory");  // a real reload: without it the compiler forwards the stored registers
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < EPT; ++r) {
       a[r] = park[r * NT + threadIdx.x];
       s[r] = X[e[r]];
       Y[e[r]] = a[r];
     }
     __syncthreads();
-    sc_v4f64 pre, pim;
-    tile_product(Y, X, m, pre, pim);
-    cd out[4];
+    cd as[EPT];
+    tile_product(Y, X, m, as);
+    cd out[EPT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      out[r] = cd{0.5 * (a[r].re + pre[r]) + 0.5 * eps * ((e[r] == et[r] ? 1.0 : 0.0) - s[r].re),
-                  0.5 * (a[r].im + pim[r]) - 0.5 * eps * s[r].im};
+    for (int r = 0; r < EPT; ++r)
+      out[r] = cd{0.5 * (a[r].re + as[r].re) + 0.5 * eps * ((e[r] == et[r] ? 1.0 : 0.0) - s[r].re),
+                  0.5 * (a[r].im + as[r].im) - 0.5 * eps * s[r].im};
     __syncthreads();  // the product's reads of image 1 are done
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Y[e[r]] = out[r];
+    for (int r = 0; r < EPT; ++r) Y[e[r]] = out[r];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < EPT; ++r) {
       const cd rt = Y[et[r]];
       a[r] = cd{0.5 * (out[r].re + rt.re), 0.5 * (out[r].im - rt.im)};
       if (e[r] == et[r]) a[r].im = 0.0;
@@ -216,18 +236,18 @@ struct Proc64 {
   }
 
   // CP projection (process.py:270-277): eigh on the lower triangle, clip at eps, rebuild
-  __device__ static void cp_project(cd (&a)[4], double eps, const Map& m, double* sm, cd* park) {
+  __device__ static void cp_project(cd (&a)[EPT], double eps, const Map& m, double* sm, cd* park) {
     complete_lower(a, m, sm);
     if (is_pd(a, eps, m, sm)) return;
     clip(a, eps, m, sm, park);
   }
 
   // TP projection (process.py:259-265): C[(a,o),(b,o)] += (delta_ab - sum_o' C[(a,o'),(b,o')]) / d
-  __device__ static void tp_project(cd (&a)[4], const Map& m, double* sm) {
+  __device__ static void tp_project(cd (&a)[EPT], const Map& m, double* sm) {
     cd* X = reinterpret_cast<cd*>(sm + oImg0);
     cd* rr = reinterpret_cast<cd*>(sm + oTp);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X[m.i(r) * P + m.j] = a[r];
+    for (int r = 0; r < EPT; ++r) X[m.i(r) * P + m.j(r)] = a[r];
     __syncthreads();
     if (threadIdx.x < DQ * DQ) {
       const int ia = threadIdx.x / DQ, ib = threadIdx.x % DQ;
@@ -241,8 +261,8 @@ struct Proc64 {
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = m.i(r), ia = i / DQ, o = i % DQ, ib = m.j / DQ, o2 = m.j % DQ;
+    for (int r = 0; r < EPT; ++r) {
+      const int i = m.i(r), j = m.j(r), ia = i / DQ, o = i % DQ, ib = j / DQ, o2 = j % DQ;
       if (o == o2) {
         const cd t = rr[ia * DQ + ib];
         a[r].re += ((ia == ib ? 1.0 : 0.0) - t.re) / DQ;
@@ -254,48 +274,54 @@ struct Proc64 {
 
   // Dykstra alternation (process.py:237-257); x = this thread's elements; returns the iteration count.
   // p, q, y -- and x across the CP step -- live in `ws` (kWsComplex complex numbers of global memory per process,
-  // element r of thread t at [r * NT + t]: coalesced, L2-resident, touched a few times per iteration) so that the CP
-  // step -- four accumulator tiles, the iterate and its Hermitian part per thread -- has the 128 registers of a
-  // 1024-thread workgroup to itself.
-  static constexpr int kWsComplex = 5 * 4 * NT;  // p, q, y, x, and the clip's parked input
-  __device__ static int dykstra(cd (&x)[4], int n_iter, double tol, const Map& m, double* sm, cd* ws) {
-    cd* pw = ws + threadIdx.x;
-    cd* qw = pw + 4 * NT;
-    cd* yw = qw + 4 * NT;
-    cd* xw = yw + 4 * NT;
+  // element r of thread t at [r * NT + t]: coalesced, L2-resident, touched a few times per iteration), so the CP
+  // step's product tiles, iterate and Hermitian part are all that is live while it runs.
+  __device__ static int dykstra(cd (&x)[EPT], int n_iter, double tol, const Map&, double* sm, cd* ws) {
+    cd* base = ws + threadIdx.x;  // one live address; the blocks are constant offsets from it
+    constexpr int pw = 0, qw = EPT * NT, yw = 2 * EPT * NT, xw = 3 * EPT * NT, parkw = 4 * EPT * NT;
     int it = 0;
+    double* const sm0 = sm;
+    cd* const ws0 = ws;
     for (; it < n_iter; ++it) {
+      // Addresses are re-derived inside every iteration: left alone, the compiler hoists the ~40 global and ~50 LDS
+      // addresses of the body out of this loop and keeps them alive through the CP step (114 registers spilled).
+      int fresh = 0;
+      asm volatile("" : "+v"(fresh));
+      sm = sm0 + fresh;
+      ws = ws0 + fresh;
+      base = ws + threadIdx.x;
+      const Map m(threadIdx.x + fresh);  // (shadows the argument: the element indices are re-derived too)
       const bool first = it == 0;  // p = q = y = 0 without reading the workspace
-      cd t[4];
+      cd t[EPT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const cd p = first ? cd{0.0, 0.0} : pw[r * NT];
+      for (int r = 0; r < EPT; ++r) {
+        const cd p = first ? cd{0.0, 0.0} : base[pw + r * NT];
         t[r] = cd{x[r].re + p.re, x[r].im + p.im};
       }
       tp_project(t, m, sm);
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        cd y = first ? cd{0.0, 0.0} : yw[r * NT];
-        const cd q = first ? cd{0.0, 0.0} : qw[r * NT];
+      for (int r = 0; r < EPT; ++r) {
+        cd y = first ? cd{0.0, 0.0} : base[yw + r * NT];
+        const cd q = first ? cd{0.0, 0.0} : base[qw + r * NT];
         const cd yd{t[r].re - y.re, t[r].im - y.im};
         y.re += yd.re;
         y.im += yd.im;
-        yw[r * NT] = y;
+        base[yw + r * NT] = y;
         s0 += yd.re * q.re + yd.im * q.im;  // sum conj(y_diff) q
         s1 += yd.re * q.im - yd.im * q.re;
         t[r] = cd{y.re + q.re, y.im + q.im};
-        xw[r * NT] = x[r];
+        base[xw + r * NT] = x[r];
       }
-      cp_project(t, 1e-12, m, sm, ws + 16 * NT);
+      cp_project(t, 1e-12, m, sm, ws + parkw);
       double six[6] = {s0, s1, 0.0, 0.0, 0.0, 0.0};
-      asm volatile("" : "+v"(xw) : : "memory");  // x is really reloaded (see clip)
+      asm volatile("" : "+v"(base) : : "memory");  // x is really reloaded (see clip)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        x[r] = xw[r * NT];
-        cd p = first ? cd{0.0, 0.0} : pw[r * NT];
-        cd q = first ? cd{0.0, 0.0} : qw[r * NT];
-        const cd y = yw[r * NT];
+      for (int r = 0; r < EPT; ++r) {
+        x[r] = base[xw + r * NT];
+        cd p = first ? cd{0.0, 0.0} : base[pw + r * NT];
+        cd q = first ? cd{0.0, 0.0} : base[qw + r * NT];
+        const cd y = base[yw + r * NT];
         const cd xd{t[r].re - x[r].re, t[r].im - x[r].im};
         x[r].re += xd.re;
         x[r].im += xd.im;
@@ -308,8 +334,8 @@ struct Proc64 {
         p.im += pd.im;
         q.re += qd.re;
         q.im += qd.im;
-        pw[r * NT] = p;
-        qw[r * NT] = q;
+        base[pw + r * NT] = p;
+        base[qw + r * NT] = q;
       }
       block_sums<NT, 6>(six, sm + oRed6);
       const double crit = 2.0 * (hypot(six[0], six[1]) + hypot(six[2], six[3])) + six[4] + six[5];
@@ -323,7 +349,8 @@ struct Proc64 {
   }
 };
 
-// mode 0: Dykstra CPTP, 1: TP only, 2: CP only  (process.py:231-278); in / out [B][64][64] complex, row-major
+// mode 0: Dykstra CPTP, 1: TP only, 2: CP only  (process.py:231-278); in / out [B][64][64] complex, row-major;
+// ws: Proc64::kWsComplex complex numbers per process (modes 0 and 2)
 __global__ void __launch_bounds__(Proc64::NT) k_cptp_project64(const double* __restrict__ in, int B, int mode, int n_iter,
                                                                 double tol, double* __restrict__ out,
                                                                 int32_t* __restrict__ iters, int32_t* __restrict__ status,
@@ -331,18 +358,19 @@ __global__ void __launch_bounds__(Proc64::NT) k_cptp_project64(const double* __r
   extern __shared__ __attribute__((aligned(16))) double sm64[];
   const int b = blockIdx.x;
   if (b >= B) return;
-  const Proc64::Map m;
+  const Proc64::Map m(threadIdx.x);
   const cd* src = reinterpret_cast<const cd*>(in) + (size_t)b * Proc64::DC * Proc64::DC;
-  cd x[4];
+  cd* wsb = reinterpret_cast<cd*>(ws) + (size_t)b * Proc64::kWsComplex;
+  cd x[Proc64::EPT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) x[r] = src[m.i(r) * Proc64::DC + m.j];
+  for (int r = 0; r < Proc64::EPT; ++r) x[r] = src[m.i(r) * Proc64::DC + m.j(r)];
   int it = 0;
-  if (mode == 0) it = Proc64::dykstra(x, n_iter, tol, m, sm64, reinterpret_cast<cd*>(ws) + (size_t)b * Proc64::kWsComplex);
+  if (mode == 0) it = Proc64::dykstra(x, n_iter, tol, m, sm64, wsb);
   else if (mode == 1) Proc64::tp_project(x, m, sm64);
-  else Proc64::cp_project(x, 1e-12, m, sm64, reinterpret_cast<cd*>(ws) + (size_t)b * Proc64::kWsComplex + 16 * Proc64::NT);
+  else Proc64::cp_project(x, 1e-12, m, sm64, wsb + 4 * Proc64::EPT * Proc64::NT);
   cd* dst = reinterpret_cast<cd*>(out) + (size_t)b * Proc64::DC * Proc64::DC;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) dst[m.i(r) * Proc64::DC + m.j] = x[r];
+  for (int r = 0; r < Proc64::EPT; ++r) dst[m.i(r) * Proc64::DC + m.j(r)] = x[r];
   if (threadIdx.x == 0) {
     if (iters) iters[b] = it;
     if (status) status[b] = (x[0].re == x[0].re) ? 0 : 4;

@@ -1062,6 +1062,22 @@ int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, in
   return finish(h, flags);
 }
 
+// the same for dim x dim matrices of any size (the Choi matrices of an n-qubit channel are 4^n x 4^n: 2n-qubit objects)
+int qt_hs_dist_dim(qt_handle_t* h, int dim, const double* rho, const double* centre, int B, double* dist, int flags) {
+  QT_ENTER(h);
+  if (dim < 1 || dim > 4096 || B < 0 || (B > 0 && (!rho || !centre || !dist))) return fail(QT_ERR_ARG, "bad hs_dist arguments");
+  if (B == 0) return 0;
+  const size_t ne = (size_t)dim * dim;
+  const double *dr, *dcn;
+  double* dd;
+  if (int r = stage_in(h, h->in0, rho, (size_t)B * ne * 2, flags, &dr)) return r;
+  if (int r = stage_in(h, h->in1, centre, ne * 2, flags, &dcn)) return r;
+  if (int r = stage_out(h, h->out0, dist, (size_t)B, flags, &dd)) return r;
+  hipLaunchKernelGGL(qt::k_hs_dist, dim3(B), dim3(64), 0, h->stream, dim, dr, dcn, B, dd);
+  if (int r = fetch_out(h, dd, dist, (size_t)B, flags)) return r;
+  return finish(h, flags);
+}
+
 // ---- a16: interval.py:610-612 ------------------------------------------------------------------------
 int qt_sort_f64(qt_handle_t* h, double* x, long long n, int flags) {
   QT_ENTER(h);
@@ -1292,8 +1308,11 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
     }
     hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 15) / 16), dim3(256), 0, h->stream, dc, B * D, M, D, R, F);
     // T[(b, s)][beta] = sum_m F[(b, s)][m] V_P^+[beta][m]: real x complex = a real GEMM with 2 D interleaved columns
-    hipLaunchKernelGGL(qt::k_gemm<0>, dim3(2 * D / 16, (B * D + 15) / 16), dim3(64), 0, h->stream, B * D, 2 * D, M, F, M, 0,
-                       (const double*)h->proc.vp_pinvT, 2 * D, 0, T, 2 * D);
+    for (int b0 = 0; b0 < B; b0 += 8192) {  // (grid.y <= 65535 row tiles)
+      const int nb = B - b0 < 8192 ? B - b0 : 8192;
+      hipLaunchKernelGGL(qt::k_gemm<0>, dim3(2 * D / 16, (nb * D + 15) / 16), dim3(64), 0, h->stream, nb * D, 2 * D, M,
+                         F + (size_t)b0 * R, M, 0, (const double*)h->proc.vp_pinvT, 2 * D, 0, T + (size_t)b0 * D * D * 2, 2 * D);
+    }
     hipLaunchKernelGGL(qt::k_lifp_kron_finish, dim3(B), dim3(256), 0, h->stream, (const double*)T, (const double*)h->proc.vs_pinv,
                        B, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
     if (cptp) {

@@ -450,9 +450,11 @@ class Engine:
         rho = _c128(rho)
         centre = _c128(centre)
         single = rho.ndim == 2
-        r = rho.reshape(-1, self.d, self.d)
+        dim = rho.shape[-1]  # any square size (Choi matrices are 4^n x 4^n), not only this engine's 2^n
+        r = rho.reshape(-1, dim, dim)
+        assert centre.shape == (dim, dim)
         out = np.empty(r.shape[0])
-        self._chk(self.lib.qt_hs_dist_batch(self._h, _ptr(r), _ptr(centre), r.shape[0], _ptr(out), _capi.QT_HOST_PTR))
+        self._chk(self.lib.qt_hs_dist_dim(self._h, dim, _ptr(r), _ptr(centre), r.shape[0], _ptr(out), _capi.QT_HOST_PTR))
         return out[0] if single else out
 
     def hs_dist_dev(self, rho, centre, out):

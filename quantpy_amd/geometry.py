@@ -14,7 +14,8 @@ def hs_dst(A, B):
 
     a, b = _as_matrix(A), _as_matrix(B)
     n_qubits = int(np.log2(a.shape[0]))
-    dist = float(get_engine(n_qubits).hs_dist(a, b))
+    # (the kernel takes any square size; a 64 x 64 Choi matrix of a 3-qubit channel runs on the 3-qubit engine)
+    dist = float(get_engine(n_qubits if n_qubits <= 5 else n_qubits // 2).hs_dist(a, b))
     return 0 if dist < 1e-15 else dist
 
 

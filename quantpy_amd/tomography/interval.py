@@ -372,7 +372,7 @@ class MHMCProcessInterval(ConfidenceInterval):
         self.samples = np.ascontiguousarray(chain[skip::self.thinning][: self.n_points].real)
         self.acceptance_rate = float(accepted[skip:].mean()) if total else 0.0
         if tmg.dst is hs_dst:
-            dist = get_engine(self.channel.choi.n_qubits).hs_dist(self.samples, centre)
+            dist = get_engine(self.channel.n_qubits).hs_dist(self.samples, centre)
         else:
             dist = np.array([tmg.dst(m, centre) for m in self.samples], dtype=np.float64)
         dist = np.sort(dist)
@@ -412,7 +412,7 @@ class BootstrapProcessInterval(ConfidenceInterval):
             choi = boot.point_estimate_batch(shard, method=self.method, cptp=self.cptp,
                                              states_physical=self.states_physical, states_init=self.states_init)
             if tmg.dst is hs_dst:
-                return get_engine(centre.n_qubits).hs_dist(choi, centre.matrix)
+                return get_engine(tmg.channel.n_qubits).hs_dist(choi, centre.matrix)  # 4^n x 4^n matrices on the channel's engine
             from ..qobj import Qobj
 
             return np.array([tmg.dst(Qobj(c), centre) for c in choi], dtype=np.float64)

@@ -94,3 +94,21 @@ def test_n3_states_estimator_and_batch(g3):
     assert np.linalg.eigvalsh(eng.cptp_project(g3["Q0_choi_nocptp"], mode="cp")).min() > 0
     with pytest.raises(RuntimeError):
         tmg.point_estimate("pgdb")
+
+
+def test_n3_bootstrap_process_interval_runs(g3):
+    """BootstrapProcessInterval on three qubits: resamples in the reference's stream order (one sampler call), batched
+    'lifp' + CPTP, sorted finite distances; the same seed gives the same interval."""
+    import quantpy_amd as qp
+
+    tmg = _tomograph(qp, g3, "Q0")
+    tmg.point_estimate("lifp")
+    out = []
+    for _ in range(2):
+        np.random.seed(5)
+        iv = qp.BootstrapProcessInterval(tmg, n_points=6)
+        radii, _ = iv([0.1, 0.5, 0.9])
+        assert iv.boot_counts.shape == (6, 64, 27, 8) and np.all(iv.boot_counts.sum(-1) == 10000)
+        assert np.all(np.isfinite(radii)) and np.all(np.diff(radii) >= 0) and radii[0] > 0
+        out.append(radii)
+    assert np.array_equal(out[0], out[1])

@@ -494,21 +494,11 @@ struct Large {
   }
 
   // ---- a9: NLL value + exact gradient (product POVM) -------------------------------------------------
-  // noinline: inlined into the BFGS loop, hipcc hoists the ~100 loop-invariant LDS addresses of the
-  // unrolled Pauli transforms out of that loop and, capped at 128 VGPRs by the 1024-thread workgroup,
-  // spills them (1.4 KB of scratch per thread, reloaded inside every Cholesky / Jacobi step).
-  // Out of line the LDS base in Ctx arrives as a generic pointer and every access through it would be a
-  // flat_load / flat_store (all 224 of them were); the assumption tells the compiler where it points and
-  // they become ds_read / ds_write again.
-  __device__ __attribute__((noinline)) static void nll_grad(const Ctx& cin, double xt, double& f, double& gt) {
-    Ctx c = cin;
-#if defined(__HIP_DEVICE_COMPILE__)  // (the builtin has no host-side declaration)
-    __builtin_assume(__builtin_amdgcn_is_shared(c.sm));
-#endif
-    nll_grad_inl(c, xt, f, gt);
-  }
-  // The same evaluation inlined: for kernels that evaluate ONCE (k_nll_large, k_mle_large_start).  An out-of-line
-  // callee has to save the callee-saved registers it touches (176 bytes of scratch per lane in k_nll_large).
+  // Always inlined.  Inside the BFGS loop the caller hands over a Ctx whose LDS base and thread indices it has just
+  // re-derived from values the compiler cannot see through (k_mle_large_bfgs): otherwise hipcc hoists the ~100
+  // loop-invariant LDS addresses of the unrolled Pauli transforms out of that loop and spills them (1.4 KB of scratch
+  // per lane, reloaded inside every Cholesky step).  An out-of-line version (rounds 1-2) paid the callee-saved
+  // register saves instead: 176-288 bytes of scratch per lane.
   __device__ __forceinline__ static void nll_grad_inl(const Ctx& c, double xt, double& f, double& gt) {
     double tr;
     QT_STAMP(11);
@@ -805,19 +795,23 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large_bfgs(PovmView pv, c
   const int eval_cap = (max_iter + 2) * 130;
   while (true) {  // uniform: one trial per workgroup, every thread holds the same scalars
     double ft, gt;
-    // Inlined, with the LDS base laundered through an empty asm every iteration: the compiler can then neither hoist
-    // the ~100 loop-invariant LDS addresses of the evaluation out of the loop (that is what spilled 1.4 KB per lane
-    // when it was first inlined) nor does the kernel pay the callee-saved-register saves of an out-of-line call
-    // (224 / 288 bytes of scratch per lane).
-    // (n = 5, capped at 128 VGPRs by its 1024-thread workgroup, spills 159 VGPRs that way and keeps the call.)
-    if constexpr (NQ == 4) {
+    // Inlined, with the LDS base and the per-thread indices laundered through an empty asm every iteration: the
+    // compiler can then neither hoist the ~100 loop-invariant LDS addresses of the evaluation out of the loop (that is
+    // what spilled 1.4 KB per lane when it was first inlined) nor does the kernel pay the callee-saved-register saves of
+    // an out-of-line call (224 / 288 bytes of scratch per lane).  n = 4: 0 scratch.  n = 5 (128-register cap of the
+    // 1024-thread workgroup): 188 bytes remain -- 21 stores before the loop, the reloads spread over its outer blocks,
+    // none inside a Cholesky / contraction loop; same speed as the call (0.90 ms per 256 mixed-start trials).
+    {
       typename S::Ctx ci = c;
-      int off = 0;
+      int off = 0, v0 = 0;
       asm volatile("" : "+s"(off));
       ci.sm = c.sm + off;
+      if constexpr (NQ == 5) {
+        asm volatile("" : "+v"(v0));
+        ci.t = c.t + v0, ci.i = c.i + v0, ci.j = c.j + v0, ci.e = c.e + v0;
+        ci.xm = c.xm + v0, ci.zm = c.zm + v0, ci.ny = c.ny + v0, ci.pi = c.pi + v0, ci.pj = c.pj + v0;
+      }
       S::nll_grad_inl(ci, xk + stp * pk, ft, gt);  // (barriers inside publish the parked line-search state)
-    } else {
-      S::nll_grad(c, xk + stp * pk, ft, gt);
     }
     if (++nfev > eval_cap) {
       status = 2;

@@ -764,7 +764,8 @@ k_mle_large_start(PovmView pv, const int64_t* __restrict__ counts, int B,
 }
 
 template <int NQ>
-__global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B,
+__global__ void __launch_bounds__(Large<NQ>::NT) __attribute__((amdgpu_waves_per_eu(4)))
+k_mle_large_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B,
                                                                   int max_iter, double gtol, double* __restrict__ rho,
                                                                   int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
                                                                   double* __restrict__ fun_out, int32_t* __restrict__ status_out,
@@ -798,19 +799,19 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_mle_large_bfgs(PovmView pv, c
     // Inlined, with the LDS base and the per-thread indices laundered through an empty asm every iteration: the
     // compiler can then neither hoist the ~100 loop-invariant LDS addresses of the evaluation out of the loop (that is
     // what spilled 1.4 KB per lane when it was first inlined) nor does the kernel pay the callee-saved-register saves of
-    // an out-of-line call (224 / 288 bytes of scratch per lane).  n = 4: 0 scratch.  n = 5 (128-register cap of the
-    // 1024-thread workgroup): 188 bytes remain -- 21 stores before the loop, the reloads spread over its outer blocks,
-    // none inside a Cholesky / contraction loop; same speed as the call (0.90 ms per 256 mixed-start trials).
+    // an out-of-line call (224 / 288 bytes of scratch per lane).  Both sizes are held to 128 registers -- four
+    // wavefronts per SIMD: the 1024-thread workgroup of n = 5 implies it, and at n = 4 four 256-thread workgroups per CU
+    // instead of two are worth more than the registers (209 VGPRs / 0 scratch: 0.686 ms per 1024 mixed-start trials;
+    // 128 VGPRs / 124 B: 0.570 ms).  What remains in scratch (n = 5: 188 B) is stored before the loop and reloaded in
+    // its outer blocks, none of it inside a Cholesky / contraction loop.
     {
       typename S::Ctx ci = c;
       int off = 0, v0 = 0;
       asm volatile("" : "+s"(off));
       ci.sm = c.sm + off;
-      if constexpr (NQ == 5) {
-        asm volatile("" : "+v"(v0));
-        ci.t = c.t + v0, ci.i = c.i + v0, ci.j = c.j + v0, ci.e = c.e + v0;
-        ci.xm = c.xm + v0, ci.zm = c.zm + v0, ci.ny = c.ny + v0, ci.pi = c.pi + v0, ci.pj = c.pj + v0;
-      }
+      asm volatile("" : "+v"(v0));
+      ci.t = c.t + v0, ci.i = c.i + v0, ci.j = c.j + v0, ci.e = c.e + v0;
+      ci.xm = c.xm + v0, ci.zm = c.zm + v0, ci.ny = c.ny + v0, ci.pi = c.pi + v0, ci.pj = c.pj + v0;
       S::nll_grad_inl(ci, xk + stp * pk, ft, gt);  // (barriers inside publish the parked line-search state)
     }
     if (++nfev > eval_cap) {

@@ -10,11 +10,13 @@ export TMPDIR=/tmp
 SHORT="bench.py --steps 20 --warmup 3 --no-cpu-baseline --bootstrap-points 0 --saturation-batch 0 --no-other-configs"
 # 1. per-kernel durations of the DEFAULT bench command (the line the driver records)
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o run --output-format csv -- python3 bench.py > $OUT/${TAG}_stats.log 2>&1
+echo "[$(date +%T)] stats done" >> $OUT/${TAG}_progress.txt
 # 2. HBM traffic of the dominant kernel (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o run --output-format csv -- python3 $SHORT > $OUT/${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o run --output-format csv -- python3 $SHORT > $OUT/${TAG}_write.log 2>&1
 # 3. executed instructions / busy cycles of the n = 3 kernels at a saturating batch, one counter per pass
 for C in SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY; do
+  echo "[$(date +%T)] pmc $C" >> $OUT/${TAG}_progress.txt
   rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$C -o run --output-format csv -- python3 scripts/kernel_breakdown.py 65536 > $OUT/${TAG}_pmc_$C.log 2>&1 || echo "counter $C not collected" >> $OUT/${TAG}_pmc_missing.txt
 done
 python3 scripts/summarise_profiles.py $TAG > $OUT/${TAG}_summary.json

@@ -112,3 +112,20 @@ def test_n3_bootstrap_process_interval_runs(g3):
         assert np.all(np.isfinite(radii)) and np.all(np.diff(radii) >= 0) and radii[0] > 0
         out.append(radii)
     assert np.array_equal(out[0], out[1])
+
+
+def test_n3_process_without_counts_is_nan_and_alone(g3):
+    """An input state without counts makes that process's frequencies 0 / 0 (process.py:285): its Choi matrix is NaN,
+    with and without the projection, and its neighbours in the batch are untouched."""
+    import quantpy_amd as qp
+
+    tmg = _tomograph(qp, g3, "Q0")
+    eng = tmg._engine()
+    counts = np.stack([g3["Q0_counts"], g3["Q0_counts"], g3["Q1_counts"]])
+    counts[1, 17] = 0
+    good = eng.lifp(counts[[0, 2]], cptp=False)
+    raw = eng.lifp(counts, cptp=False)
+    assert np.isnan(raw[1]).all() and np.array_equal(raw[0], good[0]) and np.array_equal(raw[2], good[1])
+    fixed, iters = eng.lifp(counts, cptp=True, return_iters=True)
+    assert np.isnan(fixed[1]).all() and not np.isnan(fixed[[0, 2]]).any()
+    assert iters[0] == int(g3["Q0_dykstra_iters"]) and iters[2] == int(g3["Q1_dykstra_iters"])

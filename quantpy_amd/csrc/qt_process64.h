@@ -41,8 +41,8 @@ struct Proc64 {
   static constexpr int kWsComplex = 5 * EPT * NT;  // global workspace per process: p, q, y, x, the clip's parked input
 
   struct Map {  // element r of this thread: row i(r), column j(r); r = 4 * tile + accumulator slot
-    int row0, col0, r16, kq;
-    __device__ explicit Map(int tid) {
+    int row0, col0, r16, kq, tid;
+    __device__ explicit Map(int tid_) : tid(tid_) {
       const int w = tid >> 6, lane = tid & 63;
       row0 = 16 * (w >> 1), col0 = 32 * (w & 1), r16 = lane & 15, kq = lane >> 4;
     }
@@ -61,27 +61,83 @@ struct Proc64 {
     return s;
   }
 
-  // (re, im) of this wavefront's two tiles of A B (element r of the result in c[r]); no barrier inside
-  __device__ __forceinline__ static void tile_product(const cd* A, const cd* B, const Map& m, cd (&c)[EPT]) {
+  // Y = X X and the final A S are Hermitian products, so only the 10 tiles on and above the diagonal of the 4 x 4 tile
+  // grid are computed and the 6 below are written as their mirror images.  Which wavefront computes what is decoupled
+  // there from which thread owns which element: wavefronts 0, 1 take two tiles each (row 0), the other six one each,
+  // i.e. 3 + 3 + 2 + 2 tiles on the four SIMDs (wavefronts w and w + 4 share one) instead of 4 each.
+  // X' = X W is NOT mirrored although it is Hermitian too up to the commutator of X with the rounded Y: measured (GPU and
+  // a NumPy model of the same iteration, scripts/cp_accuracy_probe.py), replacing its lower tiles by the mirror of the
+  // upper ones takes the agreement with an eigh-based clip from 1e-15 to 1e-11 -- the substitution injects a
+  // non-commuting perturbation every step and the iteration has no contraction for those.  It is computed in full, each
+  // wavefront its own two tiles.
+  struct Work {
+    int row0, col0, r16, kq;
+    bool two;  // a second tile at col0 + 16
+    __device__ explicit Work(int tid) {
+      const int w = tid >> 6, lane = tid & 63;
+      row0 = 16 * ((0xE950 >> (2 * w)) & 3);  // tile rows    0 0 1 1 1 2 2 3
+      col0 = 16 * ((0xFB98 >> (2 * w)) & 3);  // tile columns 0 2 1 2 3 2 3 3
+      two = w < 2;
+      r16 = lane & 15, kq = lane >> 4;
+    }
+  };
+
+  // tile(s) (row0, col0 [, col0 + 16]) of A B into registers (c[0..3]: first tile, c[4..7]: second); no barrier inside
+  __device__ __forceinline__ static void tiles(const cd* A, const cd* B, int row0, int col0, bool two, int r16, int kq,
+                                               cd (&c)[EPT]) {
     sc_v4f64 re0 = {0.0, 0.0, 0.0, 0.0}, im0 = re0, re1 = re0, im1 = re0;
-    const cd* ap = A + (m.row0 + m.r16) * P + m.kq;
-    const cd* bp = B + m.kq * P + m.col0 + m.r16;
+    const cd* ap = A + (row0 + r16) * P + kq;
+    const cd* bp = B + kq * P + col0 + r16;
+    if (two) {  // wave-uniform
 #pragma unroll 4
-    for (int k0 = 0; k0 < DC; k0 += 4) {
-      const cd a = ap[k0], b0 = bp[k0 * P], b1 = bp[k0 * P + 16];
-      re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, re0, 0, 0, 0);
-      im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.im, im0, 0, 0, 0);
-      re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.re, re1, 0, 0, 0);
-      im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.im, im1, 0, 0, 0);
-      re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b0.im, re0, 0, 0, 0);
-      im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.re, im0, 0, 0, 0);
-      re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b1.im, re1, 0, 0, 0);
-      im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b1.re, im1, 0, 0, 0);
+      for (int k0 = 0; k0 < DC; k0 += 4) {
+        const cd a = ap[k0], b0 = bp[k0 * P], b1 = bp[k0 * P + 16];
+        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.im, im0, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.re, re1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.im, im1, 0, 0, 0);
+        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b0.im, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.re, im0, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b1.im, re1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b1.re, im1, 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int k0 = 0; k0 < DC; k0 += 4) {
+        const cd a = ap[k0], b0 = bp[k0 * P];
+        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.im, im0, 0, 0, 0);
+        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b0.im, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.re, im0, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       c[r] = cd{re0[r], im0[r]};
       c[4 + r] = cd{re1[r], im1[r]};
+    }
+  }
+  // the Hermitian products: this wavefront's share of the upper tiles
+  __device__ __forceinline__ static void tile_product(const cd* A, const cd* B, const Work& wk, cd (&c)[EPT]) {
+    tiles(A, B, wk.row0, wk.col0, wk.two, wk.r16, wk.kq, c);
+  }
+  // a general product: this wavefront's own two tiles (element r of the result in c[r])
+  __device__ __forceinline__ static void own_product(const cd* A, const cd* B, const Map& m, cd (&c)[EPT]) {
+    tiles(A, B, m.row0, m.col0, true, m.r16, m.kq, c);
+  }
+
+  // the computed tile(s) into image D, and their conjugate transposes into the mirror positions below the diagonal
+  __device__ __forceinline__ static void store_tiles(cd* D, const Work& wk, const cd (&c)[EPT]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && !wk.two) break;
+      const int col0 = wk.col0 + 16 * t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = wk.row0 + wk.kq + 4 * r, j = col0 + wk.r16;
+        D[i * P + j] = c[4 * t + r];
+        if (col0 != wk.row0) D[j * P + i] = cd{c[4 * t + r].re, -c[4 * t + r].im};
+      }
     }
   }
 
@@ -148,7 +204,7 @@ struct Proc64 {
   // iteration of qt_signclip_wg.h; X in image 0, Y / W / A in image 1, products land in registers).
   // `park` = EPT x NT complex of global memory for this process (element r of thread t at [r * NT + t]): the input
   // waits there while the iteration runs.
-  __device__ static void clip(cd (&a)[EPT], double eps, const Map& m, double* sm, cd* park) {
+  __device__ static int clip(cd (&a)[EPT], double eps, const Map& m, double* sm, cd* park) {  // returns its product pairs
     cd* X = reinterpret_cast<cd*>(sm + oImg0);
     cd* Y = reinterpret_cast<cd*>(sm + oImg1);
     double* red = sm + oRed;
@@ -165,7 +221,7 @@ struct Proc64 {
     if (!(nrm2 > 0.0)) {  // the zero matrix (or NaN input): every eigenvalue is clipped to eps
 #pragma unroll
       for (int r = 0; r < EPT; ++r) a[r] = cd{nrm2 == 0.0 ? (e[r] == et[r] ? eps : 0.0) : nrm2, 0.0};
-      return;
+      return 0;
     }
     const double scale = 1.0 / sqrt(nrm2);
 #pragma unroll
@@ -175,34 +231,40 @@ struct Proc64 {
     }
     __syncthreads();
     bool lifting = true;
-    int ns_left = 12;
+    int ns_left = 12, steps = 0;
+    const Work wk(m.tid);  // (derived from the caller's re-derived thread index: see dykstra)
     for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (wsum returns identical bits)
       cd pr[EPT];
-      tile_product(X, X, m, pr);
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) Y[e[r]] = pr[r];  // (image 1 is idle: the last product ended behind a barrier)
+      tile_product(X, X, wk, pr);
+      store_tiles(Y, wk, pr);  // (image 1 is idle: the last product ended behind a barrier)
       __syncthreads();
       cd y[EPT];
       double rs = 0.0;
 #pragma unroll
       for (int r = 0; r < EPT; ++r) {
-        const cd yt = Y[et[r]];
-        y[r] = cd{0.5 * (pr[r].re + yt.re), 0.5 * (pr[r].im - yt.im)};  // Hermitian part
+        const cd y0 = Y[e[r]], yt = Y[et[r]];
+        y[r] = cd{0.5 * (y0.re + yt.re), 0.5 * (y0.im - yt.im)};  // Hermitian part (a no-op off the diagonal tiles)
         const double dr = (e[r] == et[r] ? 1.0 : 0.0) - y[r].re;
         rs += dr * dr + y[r].im * y[r].im;
       }
-      const double res = wsum(red, rs);  // (its first barrier also ends the transposed reads of Y)
+      const double res = wsum(red, rs);  // (its first barrier also ends the reads of Y)
       if (lifting && (res < 0.5 || k >= 40)) lifting = false;
       const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);
-      const double alpha = lifting ? 2.0 : 1.5, beta = lifting ? -1.0 : -0.5;
+      // Lifting with 1.9 x - 0.9 x^3 instead of qt_signclip_wg.h's 2 x - x^3: that one has slope -1 at x = 1, so the
+      // eigenvalues already lifted keep oscillating around 1 with an amplitude that decays only algebraically; at
+      // d = 64 their sum keeps res above 1/2 long after the last small eigenvalue has arrived (27 steps on the n = 3
+      // fixtures, 30 on a +-1 spectrum).  Slope -0.8 damps the oscillation geometrically for 5 % less growth per step:
+      // 19 steps and 9, same accuracy (NumPy model of this loop; at d <= 32 the original pair is as good or better).
+      const double alpha = lifting ? 1.9 : 1.5, beta = lifting ? -0.9 : -0.5;
 #pragma unroll
       for (int r = 0; r < EPT; ++r) Y[e[r]] = cd{fma(beta, y[r].re, e[r] == et[r] ? alpha : 0.0), beta * y[r].im};  // W
       __syncthreads();
-      tile_product(X, Y, m, pr);
+      own_product(X, Y, m, pr);
       __syncthreads();  // every wavefront has read X and W
 #pragma unroll
       for (int r = 0; r < EPT; ++r) X[e[r]] = pr[r];
       __syncthreads();
+      ++steps;
       if (last || !(res == res)) break;
     }
     // S = sign(A) sits in X.  R = (A + A S) / 2 + eps (I - S) / 2
@@ -215,14 +277,21 @@ struct Proc64 {
       Y[e[r]] = a[r];
     }
     __syncthreads();
-    cd as[EPT];
-    tile_product(Y, X, m, as);
+    {
+      cd pr[EPT];
+      tile_product(Y, X, wk, pr);  // A S, Hermitian as well (A and its sign commute)
+      __syncthreads();             // the product's reads of image 1 are done
+      store_tiles(Y, wk, pr);
+    }
+    __syncthreads();
     cd out[EPT];
 #pragma unroll
-    for (int r = 0; r < EPT; ++r)
-      out[r] = cd{0.5 * (a[r].re + as[r].re) + 0.5 * eps * ((e[r] == et[r] ? 1.0 : 0.0) - s[r].re),
-                  0.5 * (a[r].im + as[r].im) - 0.5 * eps * s[r].im};
-    __syncthreads();  // the product's reads of image 1 are done
+    for (int r = 0; r < EPT; ++r) {
+      const cd as = Y[e[r]];
+      out[r] = cd{0.5 * (a[r].re + as.re) + 0.5 * eps * ((e[r] == et[r] ? 1.0 : 0.0) - s[r].re),
+                  0.5 * (a[r].im + as.im) - 0.5 * eps * s[r].im};
+    }
+    __syncthreads();  // everybody has its elements of A S
 #pragma unroll
     for (int r = 0; r < EPT; ++r) Y[e[r]] = out[r];
     __syncthreads();
@@ -233,13 +302,15 @@ struct Proc64 {
       if (e[r] == et[r]) a[r].im = 0.0;
     }
     __syncthreads();
+    return steps;
   }
 
-  // CP projection (process.py:270-277): eigh on the lower triangle, clip at eps, rebuild
-  __device__ static void cp_project(cd (&a)[EPT], double eps, const Map& m, double* sm, cd* park) {
+  // CP projection (process.py:270-277): eigh on the lower triangle, clip at eps, rebuild.  Returns the number of
+  // sign-iteration steps it took (0: the matrix was positive definite and is returned as it came).
+  __device__ static int cp_project(cd (&a)[EPT], double eps, const Map& m, double* sm, cd* park) {
     complete_lower(a, m, sm);
-    if (is_pd(a, eps, m, sm)) return;
-    clip(a, eps, m, sm, park);
+    if (is_pd(a, eps, m, sm)) return 0;
+    return clip(a, eps, m, sm, park);
   }
 
   // TP projection (process.py:259-265): C[(a,o),(b,o)] += (delta_ab - sum_o' C[(a,o'),(b,o')]) / d
@@ -367,7 +438,7 @@ __global__ void __launch_bounds__(Proc64::NT) k_cptp_project64(const double* __r
   int it = 0;
   if (mode == 0) it = Proc64::dykstra(x, n_iter, tol, m, sm64, wsb);
   else if (mode == 1) Proc64::tp_project(x, m, sm64);
-  else Proc64::cp_project(x, 1e-12, m, sm64, wsb + 4 * Proc64::EPT * Proc64::NT);
+  else it = Proc64::cp_project(x, 1e-12, m, sm64, wsb + 4 * Proc64::EPT * Proc64::NT);  // (mode 2 reports the clip's steps)
   cd* dst = reinterpret_cast<cd*>(out) + (size_t)b * Proc64::DC * Proc64::DC;
 #pragma unroll
   for (int r = 0; r < Proc64::EPT; ++r) dst[m.i(r) * Proc64::DC + m.j(r)] = x[r];
@@ -396,13 +467,18 @@ __global__ void __launch_bounds__(256) k_lifp_kron_finish(const double* __restri
   cd acc[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = cd{0.0, 0.0};
-  for (int s = 0; s < DC; ++s) {
-    const cd v = vrow[s];
+  for (int s0 = 0; s0 < DC; s0 += 8) {  // eight rows of V_S^+ requested at once: the loop was one L2 round trip per s
+    cd v[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const cd w = tb[s * DC + b0 + k];
-      acc[k].re += v.re * w.re - v.im * w.im;
-      acc[k].im += v.re * w.im + v.im * w.re;
+    for (int u = 0; u < 8; ++u) v[u] = vrow[s0 + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const cd w = tb[(s0 + u) * DC + b0 + k];
+        acc[k].re += v[u].re * w.re - v[u].im * w.im;
+        acc[k].im += v[u].re * w.im + v[u].im * w.re;
+      }
     }
   }
   const int a = alpha / d, c = alpha % d;

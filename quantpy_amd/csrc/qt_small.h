@@ -851,13 +851,26 @@ struct Small {
   // The elimination is carried on past a non-positive pivot as L S L^dagger (S = signs), so that by
   // Sylvester's law `neg` is the number of negative eigenvalues (99 when a pivot is too small for
   // the count to mean anything) and `kneg` the first index where the leading block stops being PD.
-  __device__ static double cholesky_param(const Ctx& c, cd a, int& ok, int* neg_out = nullptr, int* kneg_out = nullptr) {
+  // SPEC (latency-bound launches only: one wave per SIMD, the fused kernel): the Gauss-Jordan inverse that
+  // lift_single_negative needs when the LAST pivot is the negative one (kneg = d - 1, the generic case for one small
+  // negative eigenvalue: natural pivot order) runs in the same sweep, step k of it beside step k of the elimination --
+  // two independent dependency chains sharing the LDS round trips.  A trial that turns out not positive definite then
+  // skips ~3 k of its ~39 k clocks (the launch ends with its slowest wave, and those are the clipped trials); a
+  // positive definite one throws the inverse away, ~1.5 k clocks it had to spare.  Same arithmetic, same bits, as the
+  // loop in lift_single_negative.  *spec_inv = this lane's element of the inverse (garbage unless kneg = d - 1).
+  template <bool SPEC = false>
+  __device__ static double cholesky_param(const Ctx& c, cd a, int& ok, int* neg_out = nullptr, int* kneg_out = nullptr,
+                                          cd* spec_inv = nullptr) {
     cd* A = c.A();
     cd* L = c.Bm();
+    cd* Vs = c.V();
     const int i = c.i, j = c.j;
     A[c.e] = a;
     int neg = 0, kneg = d - 1;
     cd lmine{0.0, 0.0};  // this lane's element of L (its column j is final after step k = j)
+    cd b = a;            // SPEC: the matrix on its way to its inverse
+    if (SPEC && i == j) b.im = 0.0;
+    if (SPEC) Vs[c.e] = b;
     wave_sync();
 #pragma unroll
     for (int k = 0; k < d; ++k) {
@@ -865,6 +878,20 @@ struct Small {
       // (v_readlane), so that 1/sqrt runs while the column is still on its way through LDS.
       const double akk = (G == 64) ? readlane_f64(a.re, k * d + k) : A[k * LD + k].re;
       const cd aik = A[i * LD + k], ajk = A[j * LD + k];
+      if constexpr (SPEC) {  // step p = k of the inverse (lift_single_negative's loop body)
+        const double piv = readlane_f64(b.re, k * d + k);
+        const cd bip = Vs[i * LD + k], bpj = Vs[k * LD + j];
+        double inv = __builtin_amdgcn_rcp(piv);
+        inv = fma(inv, fma(-piv, inv, 1.0), inv);
+        inv = fma(inv, fma(-piv, inv, 1.0), inv);
+        const cd t{bpj.re * inv, bpj.im * inv};
+        const cd e = cmul(bip, t);
+        cd nb{b.re - e.re, b.im - e.im};
+        if (j == k) nb = cd{-bip.re * inv, -bip.im * inv};
+        if (i == k) nb = (j == k) ? cd{inv, 0.0} : t;
+        b = nb;
+        if (k + 1 < d) Vs[c.e] = b;  // published by the elimination's wave_sync below
+      }
       const double mag = fabs(akk);
       const bool pos = akk > 0.0;
       if (!pos) {
@@ -898,6 +925,7 @@ struct Small {
     ok = neg == 0;
     if (neg_out) *neg_out = neg;
     if (kneg_out) *kneg_out = kneg;
+    if (SPEC && spec_inv) *spec_inv = b;
     L[c.e] = lmine;
     wave_sync();
     const cd e = L[c.pi * LD + c.pj];
@@ -915,15 +943,18 @@ struct Small {
   // Certified, not assumed: purity Tr N^2 -> 1 (then one more squaring: contamination < 1e-14),
   // lam_1 = Tr(A N) < eps, and ||A N - lam_1 N||_F <= 1e-13 ||A||_F.  Returns false (caller runs the
   // Jacobi eigensolver on the untouched input) on a slow ratio, a positive lam, or a failed check.
-  __device__ static bool lift_single_negative(const Ctx& c, cd r, int kneg, double eps, cd& out) {
+  // `inverse`: the lane's element of A^{-1} when the caller already has it (cholesky_param<true>, kneg = d - 1).
+  __device__ static bool lift_single_negative(const Ctx& c, cd r, int kneg, double eps, cd& out,
+                                              const cd* inverse = nullptr) {
     static_assert(G == 64, "one trial per wavefront: the flags below are wave-uniform");
     cd* Ai = c.A();
     cd* Vi = c.V();
     const int i = c.i, j = c.j;
     if (i == j) r.im = 0.0;
     cd b = r;
+    if (inverse) b = *inverse;
 #pragma unroll 1
-    for (int s = 0; s < d; ++s) {
+    for (int s = inverse ? d : 0; s < d; ++s) {
       const int p = s < kneg ? s : (s < d - 1 ? s + 1 : kneg);
       Ai[c.e] = b;
       const double piv = readlane_f64(b.re, p * d + p);  // from lane (p, p): no LDS wait before 1 / pivot
@@ -1002,9 +1033,11 @@ struct Small {
   // definite (its Cholesky factorisation runs through) no eigenvalue is below the clip, so
   // U max(v, 1e-15) U^dagger is the input itself (to rounding) and only the trace division is left.
   // Returns the projected element; if `xl` is non-null also the Cholesky parameter of the result.
+  template <bool SPEC = false>
   __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out, double* lscale_out = nullptr) {
     int ok, neg, kneg;
-    double x = cholesky_param(c, r, ok, &neg, &kneg);
+    cd spec_inv{0.0, 0.0};
+    double x = cholesky_param<SPEC && G == 64>(c, r, ok, &neg, &kneg, &spec_inv);
     QT_STAMP(3);
     const double tr = gsum<G>(c.i == c.j ? r.re : 0.0);
     cd out{r.re / tr, r.im / tr};
@@ -1017,9 +1050,11 @@ struct Small {
       cd proj;
       bool lifted = false;
       if constexpr (G == 64) {  // one trial per wave: neg / kneg are the same in every lane
-        if (kLiftSingleNegative && __builtin_amdgcn_readfirstlane(neg) == 1)
+        if (kLiftSingleNegative && __builtin_amdgcn_readfirstlane(neg) == 1) {
+          const int kn = __builtin_amdgcn_readfirstlane(kneg);
           lifted = __builtin_amdgcn_readfirstlane(
-                       (int)lift_single_negative(c, r, __builtin_amdgcn_readfirstlane(kneg), 1e-15, proj)) != 0;
+                       (int)lift_single_negative(c, r, kn, 1e-15, proj, SPEC && kn == d - 1 ? &spec_inv : nullptr)) != 0;
+        }
       }
       if (!lifted) proj = psd_project(c, r, 1e-15);  // whole wave runs it; PD trials keep their shortcut
       QT_STAMP(6);
@@ -1699,7 +1734,7 @@ __device__ __forceinline__ void mle_fused_body(const PovmView& pv, const int64_t
     const cd lin = S::lin_invert(c, bl);
     QT_STAMP(2);
     S::load_image(c, pv.Aw);
-    sp.rho = S::make_feasible(c, lin, &xk, &ok, &sp.lscale);
+    sp.rho = S::template make_feasible<true>(c, lin, &xk, &ok, &sp.lscale);  // one wave per SIMD: speculative inverse (cholesky_param)
   } else {
     S::load_image(c, pv.Aw);
     sp.rho = cd{c.i == c.j ? 1.0 / d : 0.0, 0.0};

@@ -264,12 +264,13 @@ def main():
     eng.timer_begin()
     for _ in range(args.steps):
         step()
-    kernel_ms = eng.timer_end() / args.steps  # HIP events on the stream the kernel runs on (waits for the last step)
+    eng.timer_stop()  # HIP events on the stream the kernel runs on; the interval is read after the region
     torch.cuda.synchronize()
     barrier()
     if use_dist:
         torch.cuda.synchronize()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    kernel_ms = eng.timer_elapsed() / args.steps
     assert torch.cuda.current_device() == dev_index  # engine calls leave the thread's device alone
 
     nit = nit_d.cpu().numpy()

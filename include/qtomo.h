@@ -83,6 +83,9 @@ int qt_set_option(qt_handle_t* h, int option, double value);
 /* hipEvent timers on the handle's stream: begin, ..., end -> elapsed milliseconds */
 int qt_timer_begin(qt_handle_t* h);
 int qt_timer_end(qt_handle_t* h, double* elapsed_ms);
+/* the two halves of qt_timer_end: record the end event (asynchronous) / wait for it and read the interval */
+int qt_timer_stop(qt_handle_t* h);
+int qt_timer_elapsed(qt_handle_t* h, double* elapsed_ms);
 
 /* ---- a1: quantpy/routines.py:14-19 generate_pauli ---------------------------------------- */
 /* out[D][d][d][2]: P_k = P_k1 (x) ... (x) P_kn, k = sum_j k_j 4^(n-1-j) */

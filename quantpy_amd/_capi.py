@@ -34,6 +34,8 @@ SIGNATURES = {
     "qt_set_option": (_c_int, [_vp, _c_int, _c_dbl]),
     "qt_timer_begin": (_c_int, [_vp]),
     "qt_timer_end": (_c_int, [_vp, ctypes.POINTER(_c_dbl)]),
+    "qt_timer_stop": (_c_int, [_vp]),
+    "qt_timer_elapsed": (_c_int, [_vp, ctypes.POINTER(_c_dbl)]),
     "qt_pauli_basis": (_c_int, [_vp, _vp, _c_int]),
     "qt_povm_kron": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _c_int]),
     "qt_set_povm": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _c_int]),

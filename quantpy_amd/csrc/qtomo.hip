@@ -435,15 +435,26 @@ int qt_timer_begin(qt_handle_t* h) {
   return 0;
 }
 
-int qt_timer_end(qt_handle_t* h, double* elapsed_ms) {
+// the end event only (asynchronous): a caller that synchronises anyway reads the interval afterwards
+int qt_timer_stop(qt_handle_t* h) {
+  QT_ENTER(h);
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  return 0;
+}
+
+int qt_timer_elapsed(qt_handle_t* h, double* elapsed_ms) {
   QT_ENTER(h);
   if (!elapsed_ms) return fail(QT_ERR_ARG, "null elapsed_ms");
-  HIPCHK(hipEventRecord(h->ev1, h->stream));
   if (int r = wait_event_spin(h->ev1)) return r;
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *elapsed_ms = ms;
   return 0;
+}
+
+int qt_timer_end(qt_handle_t* h, double* elapsed_ms) {
+  if (int r = qt_timer_stop(h)) return r;
+  return qt_timer_elapsed(h, elapsed_ms);
 }
 
 int qt_pauli_basis(qt_handle_t* h, double* out, int flags) {

@@ -159,6 +159,16 @@ class Engine:
         self._chk(self.lib.qt_timer_end(self._h, ctypes.byref(ms)))
         return ms.value
 
+    def timer_stop(self):
+        """Record the end event without waiting for it (HIP events on the engine's stream)."""
+        self._chk(self.lib.qt_timer_stop(self._h))
+
+    def timer_elapsed(self):
+        """Milliseconds between timer_begin() and timer_stop(); waits for the end event."""
+        ms = ctypes.c_double(0.0)
+        self._chk(self.lib.qt_timer_elapsed(self._h, ctypes.byref(ms)))
+        return ms.value
+
     # ---- a1 / a2 ----------------------------------------------------------------------------
     def pauli_basis(self):
         out = np.empty((self.D, self.d, self.d), dtype=np.complex128)

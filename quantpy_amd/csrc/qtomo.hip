@@ -187,8 +187,16 @@ int wait_event_spin(hipEvent_t ev) {
   return 0;
 }
 int wait_stream(qt_handle_t* h) {
-  HIPCHK(hipEventRecord(h->ev_sync, h->stream));
-  return wait_event_spin(h->ev_sync);
+  // poll the stream itself (no event packet to push through the queue first: an idle wait costs ~2 us instead of ~12)
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(h->stream);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return fail(QT_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q));
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
 }
 int finish(qt_handle_t* h, int flags) {
   HIPCHK(hipGetLastError());

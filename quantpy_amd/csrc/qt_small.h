@@ -65,11 +65,17 @@ __device__ __forceinline__ cd cmulc(cd a, cd b) {  // a * conj(b)
 __device__ __forceinline__ cd cadd(cd a, cd b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cd cscale(cd a, double s) { return {a.re * s, a.im * s}; }
 
-// LDS hand-off inside one wavefront: order this wave's LDS writes before its later reads.
+// LDS hand-off inside ONE wavefront: order this wave's LDS writes before its later reads.  The hardware already does:
+// the LDS executes the DS instructions of a wavefront in issue order, each for all 64 lanes before the next starts, so a
+// ds_read behind a ds_write of the same wave sees the data whichever lane wrote it.  What is needed is that the
+// COMPILER keeps the order (to it, another lane's slot is just a different address): a scheduling barrier plus an
+// empty asm with a memory clobber.  Rounds 1-2 used release / acquire fences at workgroup scope here, which cost an
+// `s_waitcnt lgkmcnt(0)` -- a full drain of the LDS queue, ~100 clocks -- at each of the ~100 hand-offs of a trial.
+// (Never a cross-wave hand-off: every use is inside one trial's own scratch; tables shared by a workgroup are
+// published by __syncthreads.)
 __device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");
 }
 
 // ---- group reductions on the DPP network (no LDS round trips) ---------------------------------

@@ -318,3 +318,21 @@ def test_options_and_iteration_limits(oracle):
         assert nit > 24 or st != 3  # the case is meant to go past the LDS-resident pairs
     assert np.all(i_long["nit"] >= i_fused["nit"])
     eng.close()
+
+
+def test_hs_dist_of_any_square_size_and_split_timer():
+    """qt_hs_dist_dim (Choi matrices are 4^n x 4^n, not the handle's 2^n x 2^n) against the reference formula
+    sqrt(|Tr((A - B)^2)|) / sqrt(2) (geometry.py:16-20), and the two halves of qt_timer_end."""
+    import quantpy_amd as qp
+
+    rng = np.random.default_rng(12)
+    eng = qp.get_engine(3)
+    for dim in (4, 16, 64):
+        a = rng.standard_normal((5, dim, dim)) + 1j * rng.standard_normal((5, dim, dim))
+        b = rng.standard_normal((dim, dim)) + 1j * rng.standard_normal((dim, dim))
+        want = np.array([np.sqrt(np.abs(np.trace((x - b) @ (x - b)))) / np.sqrt(2) for x in a])
+        assert np.abs(eng.hs_dist(a, b) - want).max() < 1e-12 * want.max()
+    assert qp.hs_dst(qp.Qobj(np.eye(64) / 64), qp.Qobj(np.eye(64) / 64)) == 0  # a 6-qubit object on the 3-qubit engine
+    eng.timer_begin()
+    eng.timer_stop()
+    assert 0.0 <= eng.timer_elapsed() < 50.0

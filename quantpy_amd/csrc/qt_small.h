@@ -320,13 +320,22 @@ struct Small {
   // per-trial LDS scratch, in doubles
   static constexpr int oA = 0;             // complex [d][LD]
   static constexpr int oB = oA + MAT;      // complex [d][LD]
-  static constexpr int oV = oB + MAT;      // complex [d][LD]
-  static constexpr int oVec = oV + MAT;    // [D] + one slot that always holds 0 (source of L's zero entries)
+  static constexpr int oVec = oB + MAT;    // [D] + one slot that always holds 0 (source of L's zero entries)
   static constexpr int oLam = oVec + D + 2;  // [d] (+ pad to even)
   static constexpr int oM = oLam + 2 * ((d + 1) / 2);  // rbuf[Mp], freq[Mp], bufB[Mp]
+  // The third matrix image V (eigenvectors / projector / speculative inverse: make_feasible only) lives on top of rbuf
+  // whenever rbuf is large enough: rbuf is a staging buffer of load_freq, lin_invert and nll_grad, none of which is
+  // in flight while make_feasible runs.  At n = 3 with the 216-row POVM that takes a trial from 9.2 to 8.1 KB and a
+  // 4-trial workgroup from 42.9 to 38.3 KB of LDS: FOUR workgroups per CU instead of three (the saturated batches
+  // were LDS-limited to 3 waves per SIMD with registers for 4).
+  __host__ __device__ static bool v_on_rbuf(int M) { return ((M + 1) & ~1) >= MAT; }
+  __host__ __device__ static int v_offset(int M, int R1) {
+    const int Mp = (M + 1) & ~1;
+    return v_on_rbuf(M) ? oM : oM + (R1 > 0 ? 3 : 2) * Mp;
+  }
   __host__ __device__ static int trial_doubles(int M, int R1 = 0) {
     const int Mp = (M + 1) & ~1;
-    return oM + (R1 > 0 ? 3 : 2) * Mp;
+    return oM + (R1 > 0 ? 3 : 2) * Mp + (v_on_rbuf(M) ? 0 : MAT);
   }
   __host__ __device__ static int image_doubles(int M) { return ALDS ? ((M * LDA + 1) & ~1) : 0; }
   // Index tables of a product POVM, staged once per workgroup (shared by its waves): forward stage
@@ -375,7 +384,7 @@ struct Small {
     int src_re, src_im;
     __device__ __forceinline__ cd* A() const { return reinterpret_cast<cd*>(sm + oA); }
     __device__ __forceinline__ cd* Bm() const { return reinterpret_cast<cd*>(sm + oB); }
-    __device__ __forceinline__ cd* V() const { return reinterpret_cast<cd*>(sm + oV); }
+    __device__ __forceinline__ cd* V() const { return reinterpret_cast<cd*>(sm + v_offset(M, pv.pr.enabled ? pv.pr.R1 : 0)); }
     __device__ __forceinline__ double* vec() const { return sm + oVec; }
     __device__ __forceinline__ double* lam() const { return sm + oLam; }
     __device__ __forceinline__ double* rbuf() const { return sm + oM; }

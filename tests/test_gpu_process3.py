@@ -129,3 +129,70 @@ def test_n3_process_without_counts_is_nan_and_alone(g3):
     fixed, iters = eng.lifp(counts, cptp=True, return_iters=True)
     assert np.isnan(fixed[1]).all() and not np.isnan(fixed[[0, 2]]).any()
     assert iters[0] == int(g3["Q0_dykstra_iters"]) and iters[2] == int(g3["Q1_dykstra_iters"])
+
+
+def test_n3_cptp_projection_regimes_against_eigh_dykstra(oracle):
+    """k_cptp_project64 on Choi matrices the fixtures do not reach -- already CPTP, CP but not TP, TP but far from CP,
+    a unitary channel (rank one) with noise, large noise -- against a NumPy Dykstra loop with eigh (process.py:237-278;
+    its TP step checked once against the oracle's operator form): same iteration counts, Choi to 1e-9."""
+    import quantpy_amd as qp
+
+    d, dc = 8, 64
+    rng = np.random.default_rng(64)
+    eye_d = np.eye(d)
+
+    def tp(c):
+        red = np.einsum("aobo->ab", c.reshape(d, d, d, d))
+        return c + np.kron((eye_d - red) / d, eye_d)
+
+    def cp(c):
+        w, u = np.linalg.eigh(np.tril(c) + np.tril(c, -1).conj().T)
+        return (u * np.maximum(w, 1e-12)) @ u.conj().T
+
+    def dykstra(c, n_iter=1000, tol=1e-12):
+        x = c.astype(np.complex128)
+        p = q = y = np.zeros_like(x)
+        for it in range(n_iter):
+            yd = tp(x + p) - y
+            y = y + yd
+            xd = cp(y + q) - x
+            x = x + xd
+            crit = 2 * (abs(np.sum(yd.conj() * q)) + abs(np.sum(xd.conj() * p)))
+            pd, qd = x - y, y - x
+            p, q = p + pd, q + qd
+            crit += np.linalg.norm(pd) ** 2 + np.linalg.norm(qd) ** 2
+            if crit < tol:
+                break
+        return x, it + 1
+
+    def herm(scale):
+        g = rng.standard_normal((dc, dc)) + 1j * rng.standard_normal((dc, dc))
+        return scale * (g + g.conj().T) / 2
+
+    def random_cptp(rank):
+        k = rng.standard_normal((rank, d, d)) + 1j * rng.standard_normal((rank, d, d))
+        s = sum(a.conj().T @ a for a in k)
+        w, u = np.linalg.eigh(s)
+        k = k @ ((u / np.sqrt(w)) @ u.conj().T)  # sum K^dagger K = 1
+        v = [a.T.reshape(-1) for a in k]  # v[(in, out)] = K[out][in]
+        return sum(np.outer(x, x.conj()) for x in v)  # C[(a, o), (b, o')] = sum_k K[o][a] conj(K[o'][b])
+
+    base = random_cptp(3)
+    assert np.abs(np.einsum("aobo->ab", base.reshape(d, d, d, d)) - eye_d).max() < 1e-12  # the construction is TP in this layout
+    some = herm(0.05)
+    assert np.abs(tp(some) - oracle.vec2mat(oracle.tp_projection_vec(oracle.mat2vec(some), 3))).max() < 1e-12
+    cases = {
+        "already CPTP": random_cptp(64),
+        "CP, not TP": 1.3 * random_cptp(8),
+        "unitary channel + noise": random_cptp(1) + herm(0.01),
+        "rank 3 + large noise": base + herm(0.2),
+        "indefinite": herm(1.0),
+    }
+    eng = qp.get_engine(3)
+    batch = np.stack(list(cases.values()))
+    got, iters = eng.cptp_project(batch, mode="cptp", return_iters=True)
+    for (name, c), g, it in zip(cases.items(), got, iters):
+        want, want_it = dykstra(c)
+        assert int(it) == want_it, (name, int(it), want_it)
+        assert np.abs(g - want).max() < 1e-9, (name, np.abs(g - want).max())
+        assert np.linalg.eigvalsh(g).min() > -1e-9 and np.abs(np.einsum("aobo->ab", g.reshape(d, d, d, d)) - eye_d).max() < 1e-5

@@ -71,6 +71,18 @@ struct qt_handle {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
+  // Pinned host mailbox for the small transfers of host-pointer calls (counts of a few trials in, rho / nit / status
+  // out): hipMemcpyAsync from / to pageable memory blocks the caller ~10 us per copy, a one-trial qt_mle_batch makes six.
+  // Through pinned memory they are asynchronous; outputs are copied to the caller's arrays once the stream has been
+  // waited for (drain_mailbox).  Transfers above kMailMax, or when the box is full, take the direct route.
+  struct Pending {
+    void* dst;
+    const void* src;
+    size_t bytes;
+  };
+  char* mail = nullptr;
+  size_t mail_used = 0;
+  std::vector<Pending> mail_pending;
   // POVM cache.  The dense operands A, A^T, A', A'^T ([M][D] each: 64 MB at n = 5) exist when `dense_ready`;
   // a product POVM at n >= 4 never reads them and builds them only on demand (ensure_dense), likewise the dense
   // left inverse (`pinv_ready`, compute_dense_pinv).
@@ -140,6 +152,26 @@ inline int grid_for(size_t total, int block = 256, int cap = 8192) {
   return (int)g;
 }
 
+constexpr size_t kMailCap = 1 << 20, kMailMax = 128 << 10;
+inline char* mail_alloc(qt_handle_t* h, size_t bytes) {
+  if (bytes == 0 || bytes > kMailMax) return nullptr;
+  if (!h->mail && hipHostMalloc(reinterpret_cast<void**>(&h->mail), kMailCap, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    h->mail = nullptr;
+    return nullptr;
+  }
+  const size_t at = (h->mail_used + 63) & ~(size_t)63;
+  if (at + bytes > kMailCap) return nullptr;
+  h->mail_used = at + bytes;
+  return h->mail + at;
+}
+// after the stream has been waited for: hand the outputs parked in the mailbox to the caller's arrays
+inline void drain_mailbox(qt_handle_t* h) {
+  for (const auto& p : h->mail_pending) memcpy(p.dst, p.src, p.bytes);
+  h->mail_pending.clear();
+  h->mail_used = 0;
+}
+
 // Resolve an input array: device pointer as-is, or staged copy of a host array.
 template <class T>
 int stage_in(qt_handle_t* h, DevBuf& buf, const T* src, size_t count, int flags, const T** out) {
@@ -148,7 +180,12 @@ int stage_in(qt_handle_t* h, DevBuf& buf, const T* src, size_t count, int flags,
     return 0;
   }
   HIPCHK(buf.ensure(count * sizeof(T)));
-  HIPCHK(hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  const void* from = src;
+  if (char* m = mail_alloc(h, count * sizeof(T))) {
+    memcpy(m, src, count * sizeof(T));
+    from = m;
+  }
+  HIPCHK(hipMemcpyAsync(buf.p, from, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
   *out = buf.as<T>();
   return 0;
 }
@@ -169,6 +206,11 @@ int stage_out(qt_handle_t*, DevBuf& buf, T* dst, size_t count, int flags, T** ou
 template <class T>
 int fetch_out(qt_handle_t* h, const T* dev, T* dst, size_t count, int flags) {
   if (!dst || (flags & QT_DEVICE_PTR)) return 0;
+  if (char* m = mail_alloc(h, count * sizeof(T))) {
+    HIPCHK(hipMemcpyAsync(m, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    h->mail_pending.push_back({dst, m, count * sizeof(T)});
+    return 0;
+  }
   HIPCHK(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
   return 0;
 }
@@ -191,13 +233,23 @@ int wait_stream(qt_handle_t* h) {
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     const hipError_t q = hipStreamQuery(h->stream);
-    if (q == hipSuccess) return 0;
+    if (q == hipSuccess) {
+      drain_mailbox(h);
+      return 0;
+    }
     if (q != hipErrorNotReady) return fail(QT_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q));
     if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  drain_mailbox(h);
   return 0;
 }
+// for the entry points that block on the stream themselves
+#define QT_STREAM_SYNC(h)                       \
+  do {                                          \
+    HIPCHK(hipStreamSynchronize((h)->stream));  \
+    drain_mailbox(h);                           \
+  } while (0)
 int finish(qt_handle_t* h, int flags) {
   HIPCHK(hipGetLastError());
   if (!(flags & QT_DEVICE_PTR)) return wait_stream(h);
@@ -399,6 +451,7 @@ void qt_destroy(qt_handle_t* h) {
                     &h->ws_act, &h->hess, &h->sort_alt, &h->sort_tmp})
     b->release();
   h->proc.release();
+  if (h->mail) (void)hipHostFree(h->mail);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
@@ -413,7 +466,7 @@ int qt_sync(qt_handle_t* h) {
 
 int qt_set_stream(qt_handle_t* h, void* hip_stream) {
   QT_ENTER(h);
-  HIPCHK(hipStreamSynchronize(h->stream));
+  QT_STREAM_SYNC(h);
   if (h->own_stream && h->stream) HIPCHK(hipStreamDestroy(h->stream));
   if (hip_stream) {
     h->stream = hip_stream == QT_STREAM_LEGACY ? hipStreamLegacy : static_cast<hipStream_t>(hip_stream);
@@ -500,7 +553,7 @@ static int ensure_kron_digits(qt_handle_t* h, int S1, int K1) {
   h->kron_S1 = h->kron_K1 = 0;
   HIPCHK(h->kron_dig.ensure(dig.size() * sizeof(unsigned long long)));
   HIPCHK(hipMemcpyAsync(h->kron_dig.p, dig.data(), dig.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));  // `dig` goes out of scope
+  QT_STREAM_SYNC(h);  // `dig` goes out of scope
   h->kron_S1 = S1;
   h->kron_K1 = K1;
   return 0;
@@ -577,7 +630,7 @@ static int compute_dense_pinv(qt_handle_t* h) {
   int info = 0;
   HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));
+  QT_STREAM_SYNC(h);
   if (info != 0) return fail(QT_ERR_SINGULAR, "A^T A is singular (no pivot in column %d): POVM not informationally complete", info - 1);
   h->pinv_ready = true;
   return 0;
@@ -727,7 +780,7 @@ int qt_set_povm_product(qt_handle_t* h, const double* povm1, int S1, int K1, con
   int info = 0;
   HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));
+  QT_STREAM_SYNC(h);
   if (info != 0) return fail(QT_ERR_SINGULAR, "the one-qubit table is not informationally complete");
   h->prod.T = h->pr_T.as<double>();
   h->prod.P1T = h->pr_P1T.as<double>();
@@ -1205,7 +1258,7 @@ int qt_left_inverse(qt_handle_t* h, const double* A, int rows, int cols, int is_
   HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (int r = fetch_out(h, dout, out, nel, flags)) return r;
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));
+  QT_STREAM_SYNC(h);
   if (info != 0) return fail(QT_ERR_SINGULAR, "A^T A is singular (no pivot in column %d)", info - 1);
   return 0;
 }
@@ -1240,7 +1293,7 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
     HIPCHK(hipMemcpyAsync(&info[1], h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     launch_transpose<2>(h, (const double*)ps.vp_pinv, D, M, (double*)ps.vp_pinvT);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
+    QT_STREAM_SYNC(h);
     if (info[0] != 0) return fail(QT_ERR_SINGULAR, "input states do not span the operator space (column %d)", info[0] - 1);
     if (info[1] != 0) return fail(QT_ERR_SINGULAR, "POVM is not informationally complete (column %d)", info[1] - 1);
     ps.factored = true;
@@ -1272,7 +1325,7 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
   int info = 0;
   HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));
+  QT_STREAM_SYNC(h);
   if (info != 0) return fail(QT_ERR_SINGULAR, "process design matrix is rank deficient (column %d): input states x POVM not complete", info - 1);
   h->proc_set = true;
   return 0;

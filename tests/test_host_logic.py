@@ -404,3 +404,26 @@ def test_c_sampler_other_routes_to_the_generator(monkeypatch):
             assert np.array_equal(got, _numpy_draws(n, p, 2))
         finally:
             np.random.set_bit_generator(old)
+
+
+def test_c_sampler_argument_errors_are_codes_not_crashes():
+    """qt_legacy_multinomial is plain host code: bad arguments come back as QT_ERR_ARG with a message, no GPU needed."""
+    import ctypes
+
+    from quantpy_amd import _capi
+
+    lib = _capi.load()
+    key = np.zeros(624, dtype=np.uint32)
+    pos = ctypes.c_int(624)
+    n = np.array([5], dtype=np.int64)
+    p = np.array([[0.5, 0.5]])
+    out = np.zeros((1, 2), dtype=np.int64)
+    ok = (key.ctypes.data, ctypes.byref(pos), 1, 1, n.ctypes.data, p.ctypes.data, 2, out.ctypes.data)
+    assert lib.qt_legacy_multinomial(*ok) == 0 and out.sum() == 5
+    for bad in ((None,) + ok[1:], ok[:2] + (-1,) + ok[3:], ok[:3] + (0,) + ok[4:], ok[:6] + (0,) + ok[7:], ok[:7] + (None,)):
+        assert lib.qt_legacy_multinomial(*bad) == -1 and _capi.last_error()
+    pos.value = 700
+    assert lib.qt_legacy_multinomial(*ok) == -1 and "624" in _capi.last_error()
+    pos.value = 0
+    n[0] = -3
+    assert lib.qt_legacy_multinomial(*ok) == -1

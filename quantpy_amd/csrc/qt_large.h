@@ -215,40 +215,56 @@ struct Large {
     }
     return k;
   }
+  // Bloch vector <-> matrix as Walsh-Hadamard transforms in registers.  For a fixed x-mask the d Pauli strings
+  // (x, z), z < d, have P[r][r ^ x] = (-i)^popc(x & z) (-1)^popc(r & z): the sum over r (bloch_of) or over z (matrix_of)
+  // is a length-d WHT of one (shifted) diagonal of the matrix.  Thread t = (x, lane) holds one entry of it; log2(d)
+  // butterfly stages across the d lanes of its group (quad_perm and row_ror DPP moves, ds_bpermute for the strides 4
+  // and 16) replace the d-term sums of rounds 1-2, which read d 16-byte LDS entries per thread -- 512 KB through the
+  // LDS per call at n = 5, ~9 k + ~6 k of the ~75 k clocks of an evaluation (profiles/round2_final_phase_timing_n5.txt).
+  // The result lands in the thread that owns (x, lane), not in the thread that needs it: one scatter through LDS.
+  __device__ __forceinline__ static cd wht_butterfly(cd s, cd p, bool upper) {
+    return upper ? cd{p.re - s.re, p.im - s.im} : cd{s.re + p.re, s.im + p.im};
+  }
+  __device__ __forceinline__ static cd wht_lanes(cd s) {
+    const int lane = threadIdx.x & 63;
+    s = wht_butterfly(s, cd{dpp_f64<0xB1>(s.re), dpp_f64<0xB1>(s.im)}, lane & 1);  // quad_perm [1,0,3,2]
+    s = wht_butterfly(s, cd{dpp_f64<0x4E>(s.re), dpp_f64<0x4E>(s.im)}, lane & 2);  // quad_perm [2,3,0,1]
+    s = wht_butterfly(s, cd{__shfl_xor(s.re, 4), __shfl_xor(s.im, 4)}, lane & 4);
+    s = wht_butterfly(s, cd{dpp_f64<0x128>(s.re), dpp_f64<0x128>(s.im)}, lane & 8);  // row_ror:8 = lane ^ 8 within a row
+    if constexpr (d == 32) s = wht_butterfly(s, cd{__shfl_xor(s.re, 16), __shfl_xor(s.im, 16)}, lane & 16);
+    return s;
+  }
+  // Bloch component k = c.t of the matrix image m; uses c.vec() as the exchange buffer (ends with a barrier)
   __device__ static double bloch_of(const Ctx& c, const cd* m) {
-    cd s{0.0, 0.0};
-#pragma unroll 8  // fully unrolled, hipcc issues all d 16-byte reads at once: 128 VGPRs at d = 32, the cap of a 1024-thread
-                  // workgroup -- the spills of k_nll_large<5> / k_mle_large<5> sat exactly here (ISA, round 2)
-    for (int r = 0; r < d; ++r) {
-      const cd e = m[r * LD + (r ^ c.xm)];
-      const double sg = (__popc(r & c.zm) & 1) ? -1.0 : 1.0;
-      s.re += sg * e.re;
-      s.im -= sg * e.im;
-    }
-    const double v = c.ny == 0 ? s.re : c.ny == 1 ? s.im : c.ny == 2 ? -s.re : -s.im;
-    return v / d;
+    static_assert(d == 16 || d == 32, "one WHT group = d lanes of a wavefront");
+    const int x = c.i, r = c.j;  // this thread's entry of diagonal x: M[r][r ^ x]
+    const cd e = m[r * LD + (r ^ x)];
+    const cd s = wht_lanes(cd{e.re, -e.im});  // lane index z: sum_r (-1)^popc(r & z) conj(M[r][r ^ x])
+    const int z = r, ny = __popc(x & z) & 3;
+    const double v = ny == 0 ? s.re : ny == 1 ? s.im : ny == 2 ? -s.re : -s.im;
+    double* vec = c.vec();
+    vec[pauli_index(x, z)] = v / d;
+    __syncthreads();
+    return vec[c.t];
   }
   // spread(b): bit q of b moved to bit 2q.  pauli_index(x, z) has digit bits (hi, lo) = (z_q, x_q ^ z_q), i.e.
-  // index = spread(x) ^ 3 * spread(z): one XOR per term with the per-thread spread(x) and the constant 3 * spread(z).
+  // index = spread(x) ^ 3 * spread(z).
   __host__ __device__ static constexpr int spread(int b) {
     int r = 0;
     for (int q = 0; q < NQ; ++q) r |= ((b >> q) & 1) << (2 * q);
     return r;
   }
-  __device__ static cd matrix_of(const Ctx& c, const double* v) {
-    const int x = c.i ^ c.j;
-    const int sx = spread(x);
-    double re = 0.0, im = 0.0;
-#pragma unroll 8
-    for (int z = 0; z < d; ++z) {
-      const double val = v[sx ^ (3 * spread(z))];
-      const int ny = __popc(x & z);                    // phase (-i)^ny: 1, -i, -1, i
-      const int neg = (ny ^ (ny >> 1) ^ __popc(c.i & z)) & 1;  // -1 for ny = 1, 2; times (-1)^popc(i & z)
-      const double sv = neg ? -val : val;
-      re += (ny & 1) ? 0.0 : sv;
-      im += (ny & 1) ? sv : 0.0;
-    }
-    return cd{re, im};
+  // Element (i, j) = c.e of sum_k v[k] P_k; `img` = a free d x LD image for the exchange (ends with a barrier)
+  __device__ static cd matrix_of(const Ctx& c, const double* v, cd* img) {
+    const int x = c.i, z = c.j;  // this thread's term of diagonal x
+    const double val = v[spread(x) ^ (3 * spread(z))];
+    const int ny = __popc(x & z);              // phase (-i)^ny: 1, -i, -1, i
+    const double sv = ((ny ^ (ny >> 1)) & 1) ? -val : val;
+    const cd s = wht_lanes((ny & 1) ? cd{0.0, sv} : cd{sv, 0.0});  // lane index i: M[i][i ^ x]
+    const int i = z;
+    img[i * LD + (i ^ x)] = s;
+    __syncthreads();
+    return img[c.e];
   }
 
   // ---- factorised contractions (qt_small.h for the scheme) -------------------------------------
@@ -384,7 +400,7 @@ struct Large {
       bloch_t = col_dot_dense(c, c.PinvT, c.X()) / d;  // bloch_k = sum_m Pinv[k][m] f_m / d
       c.vec()[c.t] = bloch_t;
       __syncthreads();
-      const cd r = matrix_of(c, c.vec());
+      const cd r = matrix_of(c, c.vec(), c.Aimg());
       __syncthreads();
       return r;
     }
@@ -393,7 +409,7 @@ struct Large {
     bloch_t = prod_backward(c, c.tabP()) / (c.pr.wuni * d);
     c.vec()[c.t] = bloch_t;
     __syncthreads();
-    const cd r = matrix_of(c, c.vec());
+    const cd r = matrix_of(c, c.vec(), c.Aimg());
     __syncthreads();
     return r;
   }
@@ -553,7 +569,7 @@ struct Large {
     const double tr_g_rho = -(double)d * bsum(c, wl * bl);
     vec[c.t] = wl;
     __syncthreads();
-    cd g = matrix_of(c, vec);
+    cd g = matrix_of(c, vec, c.Vimg());  // (exchange through the X overlay: free since prod_backward returned)
     QT_STAMP(17);
     g.re = -g.re;
     g.im = -g.im;

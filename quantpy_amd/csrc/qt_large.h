@@ -433,12 +433,77 @@ struct Large {
   }
 
   // ---- a8: Cholesky (image in the A overlay, factor in L) ------------------------------------------
-  // One column per step and barrier.  Measured alternatives at n = 5 / n = 4 (profiles/round2_*large*): two columns per
-  // step (half the barriers, every thread rebuilding both pivot columns) 27.4 k vs 28.7 k clocks at n = 5 but 20 %
-  // SLOWER end to end at n = 4 -- a step is a chain of dependent latencies (LDS round trip, 1/sqrt, LDS write,
-  // barrier), not issue- or barrier-bound, so neither halving the barriers nor idling the wavefronts above the pivot
-  // row changes it.  Kept: the uniform early exit at the first non-positive pivot.
-  __device__ static double cholesky_param(const Ctx& c, cd a, int& ok) {
+  // ONE wavefront runs the whole sweep, the matrix in its registers: lane (i, g) holds row i, columns
+  // [g CPL, (g + 1) CPL) (d = 32: 2 column groups x 16 columns, 64 VGPRs; d = 16: 4 x 4).  A step sends the pivot column
+  // through a double-buffered d-entry LDS buffer (written by the column group that owns it), every lane reads its row's
+  // multiplier and the CPL multipliers of its columns, and updates its registers -- the hand-offs stay inside the
+  // wavefront (wave_sync: no hardware wait).  The workgroup-wide version of rounds 1-2 was one column per BARRIER:
+  // ~1000 clocks per step at n = 5 for a chain of LDS round trip, 1/sqrt, LDS write and a 16-wave barrier, 29-32 k per
+  // sweep (two columns per step, idling the waves above the pivot row: measured, no gain -- the barrier chain stayed).
+  // Same arithmetic per element in the same order (a_ij -= (a_ik rs)(conj(a_jk) rs) for k = 0 .. min(i, j) - 1): same
+  // bits.  The other wavefronts wait at the closing barrier.  A non-positive pivot clears `ok`; the (unrolled, branch-free) sweep runs to its end.
+  __device__ static double cholesky_param_wave(const Ctx& c, cd a, int& ok) {
+    constexpr int CG = 64 / d, CPL = d / CG;  // column groups per wavefront, columns per lane
+    cd* A = c.Aimg();
+    cd* L = c.L();
+    A[c.e] = a;
+    L[c.e] = cd{0.0, 0.0};
+    double* flag = c.red() + 31;
+    __syncthreads();
+    if (threadIdx.x < 64) {  // (wave-uniform)
+      const int i = threadIdx.x % d, g = threadIdx.x / d, j0 = g * CPL;
+      cd* col = c.Vimg();  // 2 x d entries of the X overlay (scratch here)
+      cd r[CPL];
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) r[q] = A[i * LD + j0 + q];
+      bool pd = true;
+      // (fully unrolled so that r[] is indexed by constants and stays in registers; branch-free: after a non-positive
+      //  pivot the sweep runs on, on numbers nobody reads)
+#pragma unroll
+      for (int k = 0; k < d; ++k) {
+        constexpr int kDummy = 0;
+        (void)kDummy;
+        const int kg = k / CPL, kq = k % CPL;
+        // the pivot from the register of lane (k, kg); the owners of column k publish it already scaled: l_ik = a_ik / sqrt(a_kk)
+        const double akk = readlane_f64(r[kq].re, kg * d + k);
+        pd = pd && (akk > 0.0);
+        const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
+        cd* cb = col + (k & 1) * d;
+        if (g == kg) {
+          const cd lik = (i == k) ? cd{akk * rs, 0.0} : cd{r[kq].re * rs, r[kq].im * rs};
+          cb[i] = lik;
+          if (i >= k) L[i * LD + k] = lik;
+        }
+        wave_sync();
+        if (k + 1 < d) {
+          const cd lik = cb[i];
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            const int j = j0 + q;
+            const cd ljk = cb[j];
+            const bool upd = i > k && j > k;
+            const double pre = lik.re * ljk.re + lik.im * ljk.im;  // l_ik conj(l_jk), as cmulc has it
+            const double pim = lik.im * ljk.re - lik.re * ljk.im;
+            r[q].re = upd ? r[q].re - pre : r[q].re;
+            r[q].im = upd ? r[q].im - pim : r[q].im;
+            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four columns at a time (register budget: 128)
+          }
+        }
+      }
+      if (threadIdx.x == 0) *flag = pd ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    ok = *flag != 0.0;
+    const cd e = L[c.pi * LD + c.pj];
+    const double x = c.pkind == 2 ? e.im : e.re;
+    __syncthreads();
+    return x;
+  }
+
+  // One column per step and workgroup barrier (rounds 1-2).  Still the form used at n = 5: the single-wavefront sweep
+  // needs 64 registers for its half rows, and under the 128-register cap of the 1024-thread workgroup the unrolled
+  // sweep spilled ~1300 registers (2.9 KB of scratch per lane).
+  __device__ static double cholesky_param_wg(const Ctx& c, cd a, int& ok) {
     cd* A = c.Aimg();
     cd* L = c.L();
     const int i = c.i, j = c.j;
@@ -468,6 +533,11 @@ struct Large {
     const double x = c.pkind == 2 ? e.im : e.re;
     __syncthreads();
     return x;
+  }
+
+  __device__ static double cholesky_param(const Ctx& c, cd a, int& ok) {
+    if constexpr (NQ == 4) return cholesky_param_wave(c, a, ok);
+    else return cholesky_param_wg(c, a, ok);
   }
 
   __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out) {

@@ -468,25 +468,25 @@ struct Large {
         const double akk = readlane_f64(r[kq].re, kg * d + k);
         pd = pd && (akk > 0.0);
         const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
-        cd* cb = col + (k & 1) * d;
-        if (g == kg) {
-          const cd lik = (i == k) ? cd{akk * rs, 0.0} : cd{r[kq].re * rs, r[kq].im * rs};
-          cb[i] = lik;
-          if (i >= k) L[i * LD + k] = lik;
-        }
+        // Branch-free on purpose: with an `if (owner)` block per unrolled step the compiler's control-flow structurisation
+        // stretched the live ranges until the d = 32 sweep spilled ~1300 registers (2.9 KB of scratch per lane) even with
+        // 256 registers allowed; the owners are picked by ADDRESS instead -- everybody else writes to a dummy slot (entry d
+        // of the column buffer, the padding column of its own row of L).
+        cd* cb = col + (k & 1) * (d + 1);
+        const bool own = g == kg;
+        const cd lik_k = (i == k) ? cd{akk * rs, 0.0} : cd{r[kq].re * rs, r[kq].im * rs};
+        // rows and columns up to the pivot take no update: their published multiplier is zero (x - 0 * y = x exactly
+        // for finite y; after a non-positive pivot the numbers may be anything, and nobody reads them)
+        cb[own ? i : d] = (i > k) ? lik_k : cd{0.0, 0.0};
+        L[(own && i >= k) ? i * LD + k : i * LD + d] = lik_k;
         wave_sync();
         if (k + 1 < d) {
           const cd lik = cb[i];
 #pragma unroll
           for (int q = 0; q < CPL; ++q) {
-            const int j = j0 + q;
-            const cd ljk = cb[j];
-            const bool upd = i > k && j > k;
-            const double pre = lik.re * ljk.re + lik.im * ljk.im;  // l_ik conj(l_jk), as cmulc has it
-            const double pim = lik.im * ljk.re - lik.re * ljk.im;
-            r[q].re = upd ? r[q].re - pre : r[q].re;
-            r[q].im = upd ? r[q].im - pim : r[q].im;
-            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four columns at a time (register budget: 128)
+            const cd ljk = cb[j0 + q];
+            r[q].re -= lik.re * ljk.re + lik.im * ljk.im;  // l_ik conj(l_jk), as cmulc has it
+            r[q].im -= lik.im * ljk.re - lik.re * ljk.im;
           }
         }
       }
@@ -500,9 +500,9 @@ struct Large {
     return x;
   }
 
-  // One column per step and workgroup barrier (rounds 1-2).  Still the form used at n = 5: the single-wavefront sweep
-  // needs 64 registers for its half rows, and under the 128-register cap of the 1024-thread workgroup the unrolled
-  // sweep spilled ~1300 registers (2.9 KB of scratch per lane).
+  // One column per step and workgroup barrier (rounds 1-2).  Still the form used at n = 5: there the single-wavefront sweep
+  // (64 registers of matrix per lane, 17 LDS reads and 16 complex multiply-adds per lane and step) measured the SAME time --
+  // 0.153 ms per 256 'mle' trials either way, 1.12 vs 1.14 ms per 2048 -- and left 32 bytes of scratch in the start kernel.
   __device__ static double cholesky_param_wg(const Ctx& c, cd a, int& ok) {
     cd* A = c.Aimg();
     cd* L = c.L();

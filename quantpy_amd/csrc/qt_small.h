@@ -506,7 +506,33 @@ struct Small {
   }
 
   // b_k = Re Tr(P_k M^dagger) / d for the matrix held in LDS `m` (qobj.py:132).
+  // n = 3 (one trial per wavefront, lane = 8 x + r): as in qt_large.h, for a fixed x-mask the eight strings (x, z) make
+  // the sum over r a length-8 Walsh-Hadamard transform of the shifted diagonal M[r][r ^ x] -- one LDS read and three
+  // butterfly stages across the lanes (two quad_perm DPP moves, one ds_bpermute) instead of eight reads and eight
+  // sign-and-accumulate steps per lane (~85 -> ~40 vector instructions); the value lands in lane (x, z) and goes to
+  // lane k = pauli_index(x, z) through c.vec(), which the caller fills with the Bloch vector anyway.
+  __device__ __forceinline__ static cd wht_step(cd s, cd p, bool upper) {
+    return upper ? cd{p.re - s.re, p.im - s.im} : cd{s.re + p.re, s.im + p.im};
+  }
   __device__ static double bloch_of(const Ctx& c, const cd* m) {
+    if constexpr (NQ == 3) {
+      const int x = c.i, r = c.j, lane = threadIdx.x & 63;
+      const cd e = m[r * LD + (r ^ x)];
+      cd s{e.re, -e.im};
+      s = wht_step(s, cd{dpp_f64<0xB1>(s.re), dpp_f64<0xB1>(s.im)}, lane & 1);
+      s = wht_step(s, cd{dpp_f64<0x4E>(s.re), dpp_f64<0x4E>(s.im)}, lane & 2);
+      s = wht_step(s, cd{__shfl_xor(s.re, 4), __shfl_xor(s.im, 4)}, lane & 4);
+      const int z = r;
+      const double v = re_phase(__popc(x & z) & 3, s) / d;
+      // pauli_index(x, z): digit bits (hi, lo) = (z_q, x_q ^ z_q) = spread(x) ^ 3 spread(z)
+      const int sx = (x & 1) | ((x & 2) << 1) | ((x & 4) << 2), sz = (z & 1) | ((z & 2) << 1) | ((z & 4) << 2);
+      double* vec = c.vec();
+      vec[sx ^ (3 * sz)] = v;
+      wave_sync();
+      const double mine = vec[c.l];
+      wave_sync();
+      return mine;
+    }
     cd s{0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < d; ++r) {

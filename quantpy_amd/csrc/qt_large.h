@@ -442,102 +442,84 @@ struct Large {
   // sweep (two columns per step, idling the waves above the pivot row: measured, no gain -- the barrier chain stayed).
   // Same arithmetic per element in the same order (a_ij -= (a_ik rs)(conj(a_jk) rs) for k = 0 .. min(i, j) - 1): same
   // bits.  The other wavefronts wait at the closing barrier.  A non-positive pivot clears `ok`; the (unrolled, branch-free) sweep runs to its end.
+  template <int WAVES>
   __device__ static double cholesky_param_wave(const Ctx& c, cd a, int& ok) {
-    constexpr int CG = 64 / d, CPL = d / CG;  // column groups per wavefront, columns per lane
+    // WAVES wavefronts hold the matrix in registers: lane (i, g) of the first 64 WAVES threads has row i, columns
+    // [g CPL, (g + 1) CPL).  WAVES = 1: hand-offs inside the wavefront (wave_sync).  WAVES = 4 (n = 5: 4 columns per lane):
+    // one workgroup barrier per step, which the other wavefronts only pass through -- against the one-element-per-thread
+    // form this moves 32 + 256 x 5 LDS entries per step instead of 1024 x 4 (that form is LDS-bandwidth bound: 64 KB per
+    // step), and against one wavefront alone it has a quarter of the multiply-adds per lane.
+    constexpr int LANES = 64 * WAVES, CG = LANES / d, CPL = d / CG;  // column groups, columns per lane
+    static_assert(CG * CPL == d && LANES <= NT, "the column groups tile the matrix");
     cd* A = c.Aimg();
     cd* L = c.L();
     A[c.e] = a;
     L[c.e] = cd{0.0, 0.0};
-    double* flag = c.red() + 31;
+    double* flag = c.red() + 24;  // [WAVES] verdicts
     __syncthreads();
-    if (threadIdx.x < 64) {  // (wave-uniform)
-      const int i = threadIdx.x % d, g = threadIdx.x / d, j0 = g * CPL;
-      cd* col = c.Vimg();  // 2 x d entries of the X overlay (scratch here)
-      cd r[CPL];
+    const bool worker = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < LANES;  // provably wave-uniform: scalar branches below
+    const int i = threadIdx.x % d, g = (threadIdx.x / d) % CG, j0 = g * CPL;
+    cd* col = c.Vimg();  // 2 x (d + 1) entries of the X overlay (scratch here)
+    cd r[CPL];
 #pragma unroll
-      for (int q = 0; q < CPL; ++q) r[q] = A[i * LD + j0 + q];
-      bool pd = true;
-      // (fully unrolled so that r[] is indexed by constants and stays in registers; branch-free: after a non-positive
-      //  pivot the sweep runs on, on numbers nobody reads)
+    for (int q = 0; q < CPL; ++q) r[q] = worker ? A[i * LD + j0 + q] : cd{0.0, 0.0};
+    bool pd = true;
+    // (fully unrolled so that r[] is indexed by constants and stays in registers; branch-free: after a non-positive
+    //  pivot the sweep runs on, on numbers nobody reads)
 #pragma unroll
-      for (int k = 0; k < d; ++k) {
-        constexpr int kDummy = 0;
-        (void)kDummy;
-        const int kg = k / CPL, kq = k % CPL;
-        // the pivot from the register of lane (k, kg); the owners of column k publish it already scaled: l_ik = a_ik / sqrt(a_kk)
-        const double akk = readlane_f64(r[kq].re, kg * d + k);
-        pd = pd && (akk > 0.0);
-        const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
-        // Branch-free on purpose: with an `if (owner)` block per unrolled step the compiler's control-flow structurisation
-        // stretched the live ranges until the d = 32 sweep spilled ~1300 registers (2.9 KB of scratch per lane) even with
-        // 256 registers allowed; the owners are picked by ADDRESS instead -- everybody else writes to a dummy slot (entry d
-        // of the column buffer, the padding column of its own row of L).
-        cd* cb = col + (k & 1) * (d + 1);
-        const bool own = g == kg;
-        const cd lik_k = (i == k) ? cd{akk * rs, 0.0} : cd{r[kq].re * rs, r[kq].im * rs};
-        // rows and columns up to the pivot take no update: their published multiplier is zero (x - 0 * y = x exactly
-        // for finite y; after a non-positive pivot the numbers may be anything, and nobody reads them)
+    for (int k = 0; k < d; ++k) {
+      const int kg = k / CPL, kq = k % CPL;
+      // the pivot from the register of lane (k, kg) -- it sits in the wavefront that owns column k, the only one whose
+      // value of it is used; the owners publish the column already scaled: l_ik = a_ik / sqrt(a_kk)
+      const double akk = readlane_f64(r[kq].re, (kg * d + k) & 63);
+      const bool own = worker && g == kg;
+      pd = pd && (!own || akk > 0.0);
+      const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
+      // Branch-free on purpose: with an `if (owner)` block per unrolled step the compiler's control-flow structurisation
+      // stretched the live ranges until the d = 32 sweep spilled ~1300 registers (2.9 KB of scratch per lane) even with
+      // 256 registers allowed; the owners are picked by ADDRESS instead -- everybody else writes to a dummy slot (entry d
+      // of the column buffer, the padding column of its own row of L).
+      cd* cb = col + (k & 1) * (d + 1);
+      const cd lik_k = (i == k) ? cd{akk * rs, 0.0} : cd{r[kq].re * rs, r[kq].im * rs};
+      // rows and columns up to the pivot take no update: their published multiplier is zero (x - 0 * y = x exactly
+      // for finite y; after a non-positive pivot the numbers may be anything, and nobody reads them)
+      if (worker) {  // (scalar branch: the other wavefronts only keep the barrier count)
         cb[own ? i : d] = (i > k) ? lik_k : cd{0.0, 0.0};
         L[(own && i >= k) ? i * LD + k : i * LD + d] = lik_k;
-        wave_sync();
-        if (k + 1 < d) {
-          const cd lik = cb[i];
+      }
+      if constexpr (WAVES == 1) wave_sync();
+      else __syncthreads();
+      if (worker && k + 1 < d) {
+        const cd lik = cb[i];
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) {
-            const cd ljk = cb[j0 + q];
-            r[q].re -= lik.re * ljk.re + lik.im * ljk.im;  // l_ik conj(l_jk), as cmulc has it
-            r[q].im -= lik.im * ljk.re - lik.re * ljk.im;
-          }
+        for (int q = 0; q < CPL; ++q) {
+          const cd ljk = cb[j0 + q];
+          r[q].re -= lik.re * ljk.re + lik.im * ljk.im;  // l_ik conj(l_jk), as cmulc has it
+          r[q].im -= lik.im * ljk.re - lik.re * ljk.im;
         }
       }
-      if (threadIdx.x == 0) *flag = pd ? 1.0 : 0.0;
     }
+    // every worker wavefront reports the pivots of the columns it owned
+    const bool all_pd = __all(pd);
+    if (worker && (threadIdx.x & 63) == 0) flag[threadIdx.x >> 6] = all_pd ? 1.0 : 0.0;
     __syncthreads();
-    ok = *flag != 0.0;
+    bool okb = true;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) okb = okb && flag[w] != 0.0;
+    ok = okb;
     const cd e = L[c.pi * LD + c.pj];
     const double x = c.pkind == 2 ? e.im : e.re;
     __syncthreads();
     return x;
   }
 
-  // One column per step and workgroup barrier (rounds 1-2).  Still the form used at n = 5: there the single-wavefront sweep
-  // (64 registers of matrix per lane, 17 LDS reads and 16 complex multiply-adds per lane and step) measured the SAME time --
-  // 0.153 ms per 256 'mle' trials either way, 1.12 vs 1.14 ms per 2048 -- and left 32 bytes of scratch in the start kernel.
-  __device__ static double cholesky_param_wg(const Ctx& c, cd a, int& ok) {
-    cd* A = c.Aimg();
-    cd* L = c.L();
-    const int i = c.i, j = c.j;
-    A[c.e] = a;
-    L[c.e] = cd{0.0, 0.0};
-    ok = 1;
-    __syncthreads();
-    for (int k = 0; k < d; ++k) {
-      const double akk = A[k * LD + k].re;
-      if (!(akk > 0.0)) {  // not positive definite: nobody reads the rest of the factor (uniform: every thread sees a_kk)
-        ok = 0;
-        break;
-      }
-      const double rs = fast_rsqrt(akk > 1e-300 ? akk : 1e-300);
-      const cd aik = A[i * LD + k], ajk = A[j * LD + k];
-      const cd lik{aik.re * rs, aik.im * rs}, ljk{ajk.re * rs, ajk.im * rs};
-      if (j == k && i >= k) L[c.e] = (i == k) ? cd{akk * rs, 0.0} : lik;
-      if (i > k && j > k) {
-        const cd p = cmulc(lik, ljk);
-        a.re -= p.re;
-        a.im -= p.im;
-        A[c.e] = a;
-      }
-      __syncthreads();
-    }
-    const cd e = L[c.pi * LD + c.pj];
-    const double x = c.pkind == 2 ? e.im : e.re;
-    __syncthreads();
-    return x;
-  }
-
+  // n = 4: one wavefront (4 columns per lane, no barrier).  n = 5: four wavefronts (4 columns per lane) and a barrier per
+  // step -- measured against the one-element-per-thread sweep of rounds 1-2 (0.152 ms per 256 'mle' trials) and against one
+  // wavefront with 16 columns per lane (0.153 ms, 32 B of scratch): 0.148 ms; the 16-wavefront barrier itself is most of
+  // what a step still costs.
   __device__ static double cholesky_param(const Ctx& c, cd a, int& ok) {
-    if constexpr (NQ == 4) return cholesky_param_wave(c, a, ok);
-    else return cholesky_param_wg(c, a, ok);
+    if constexpr (NQ == 4) return cholesky_param_wave<1>(c, a, ok);
+    else return cholesky_param_wave<4>(c, a, ok);
   }
 
   __device__ static cd make_feasible(const Ctx& c, cd r, double* xl, int* ok_out) {

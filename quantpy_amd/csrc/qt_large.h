@@ -162,6 +162,13 @@ struct Large {
     // when it fits (QT_LAUNCH_LARGE_X)
     if (pv.extra > 0 && counts) cache = reinterpret_cast<uint32_t*>(smem + pv.extra);
     c.cnt = cache;
+    // Per-setting totals for the shots check, from the values of the load pass itself: the K outcomes of a setting are K
+    // neighbouring rows, i.e. K neighbouring lanes of one of the eight values a thread holds, and a DPP butterfly sums
+    // them (row totals, plus the neighbouring row for K = 32).  The check used to re-read the counts afterwards, thread s
+    // walking the K values of setting s one dependent L2 round trip at a time: ~12 k of the 22 k clocks this function
+    // took at n = 5.  Needs K = 16 or 32 and the whole trial in one pass; otherwise the re-read below.
+    const bool seg = counts && pv.Ns && (pv.K == 16 || pv.K == 32) && c.M <= 8 * NT;  // uniform
+    double segsum[8];
     if (counts) {
       // eight rows per thread and pass, every load of a pass requested before the first is used (as a plain loop each
       // iteration waited out its own HBM round trip: the counts are the only cold read of a trial, 62 KB at n = 5)
@@ -177,20 +184,37 @@ struct Large {
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          if (m0 + u * NT < c.M) {
-            part += (double)v[u];
-            if (cache) {  // the natural-order count lands at its R-order slot
-              cache[ri[u]] = (uint32_t)v[u];
-              wide |= (v[u] >> 32) != 0;
-            }
+          const bool valid = m0 + u * NT < c.M;
+          const double dv = valid ? (double)v[u] : 0.0;
+          part += dv;
+          if (valid && cache) {  // the natural-order count lands at its R-order slot
+            cache[ri[u]] = (uint32_t)v[u];
+            wide |= (v[u] >> 32) != 0;
+          }
+          if (seg) {  // (every lane takes part: rows past M count as zero)
+            double sv = dv;
+            sv += dpp_f64<0xB1>(sv);
+            sv += dpp_f64<0x4E>(sv);
+            sv += dpp_f64<0x141>(sv);
+            sv += dpp_f64<0x140>(sv);                          // every lane: the total of its row of 16
+            if (pv.K == 32) sv += dpp_f64<0x142, 0xA>(sv);     // rows 1, 3: + the row before (row_bcast15)
+            segsum[u] = sv;
           }
         }
       }
     }
     c.tot = bsum(c, part);  // (barriers inside also publish the tables and the count cache)
-    // shots check (state.py:138-141, 194-197): thread s sums the K outcomes of setting s (L2 hits: just read)
+    // shots check (state.py:138-141, 194-197)
     double bad = 0.0;
-    if (counts && pv.Ns) {
+    if (seg) {
+      const int lane = c.t & 63;
+      const bool holder = pv.K == 32 ? (lane & 31) == 31 : (lane & 15) == 15;  // last lane of a setting has its total
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = c.t + u * NT;
+        if (holder && m < c.M && !shots_match(segsum[u], c.tot, pv.Ns[m / pv.K], pv.ns_tot)) bad = 1.0;
+      }
+    } else if (counts && pv.Ns) {  // thread s sums the K outcomes of setting s (L2 hits: just read)
       for (int s = c.t; s < pv.S; s += NT) {
         double t = 0.0;
         for (int k = 0; k < pv.K; ++k) t += (double)counts[s * pv.K + k];

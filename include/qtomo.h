@@ -132,6 +132,18 @@ int qt_mat_from_bloch(qt_handle_t* h, const double* bloch, int B, double* mat, i
 int qt_legacy_multinomial(uint32_t* mt_key, int* mt_pos, long long rows, int period, const int64_t* n,
                           const double* pvals, int K, int64_t* out);
 
+/* The same draws for callers that do NOT need the reference's stream (opt-in; state.py:109-114 only fixes the
+ * distribution): row r is a multinomial(n[s], pvals[s]), s = (first_row + r) % period, made on the GPU by one thread
+ * from its own Philox4x32-10 stream keyed by (seed, first_row + r) through the same conditional BTPE / inversion
+ * binomials -- so the table depends on (seed, global row index) only, however the rows are split over calls or ranks,
+ * and with QT_DEVICE_PTR the counts never leave HBM on their way to qt_lin/mle_batch.  n[period], pvals[period][K],
+ * out[rows][K].  Host-pointer calls check pvals like RandomState.multinomial does (QT_ERR_ARG); device-pointer calls
+ * clamp each conditional probability into [0, 1] (a NaN counts as 0). */
+int qt_device_multinomial(qt_handle_t* h, uint64_t seed, uint64_t first_row, long long rows, int period,
+                          const int64_t* n, const double* pvals, int K, int64_t* out, int flags);
+/* The generator block behind it, on the host, for known-answer tests: out[4] = Philox4x32-10(ctr[4], key[2]). */
+void qt_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out);
+
 /* ---- a6 + a7: state.py:191-202 _point_estimate_lin, :267-273 _make_feasible ---------------- */
 /* counts[B][S][K] int64 -> rho[B][d][d][2].  physical != 0: eigenvalues clipped at 1e-15 and
  * the trace renormalised.  bloch_out (nullable): the linear-inversion Bloch vector [B][D]. */

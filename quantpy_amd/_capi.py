@@ -56,6 +56,9 @@ SIGNATURES = {
     "qt_sort_f64": (_c_int, [_vp, _vp, ctypes.c_longlong, _c_int]),
     "qt_sorted_quantiles": (_c_int, [_vp, _vp, ctypes.c_longlong, _vp, _c_int, _vp, _c_int]),
     "qt_legacy_multinomial": (_c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp]),
+    "qt_device_multinomial": (_c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp,
+                                       _c_int]),
+    "qt_philox4x32_10": (None, [_vp, _vp, _vp]),
     "qt_process_setup": (_c_int, [_vp, _vp, _c_int]),
     "qt_process_get_operators": (_c_int, [_vp, _vp, _vp, _c_int]),
     "qt_process_get_factors": (_c_int, [_vp, _vp, _vp, _c_int]),

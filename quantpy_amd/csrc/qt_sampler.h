@@ -11,8 +11,11 @@
 // back for `np.random.set_state()`.  tests/test_host_logic.py pins it bit for bit against numpy.random itself
 // (counts and final generator state) over the (n, p) regimes the two branches cover.
 //
-// Plain host C++ -- no device code, no handle; compiled into libqtomo.so because that is the C ABI the drop-in
-// binds.  Floating-point contraction is off in here: every product and sum rounds as NumPy's build rounds it.
+// The binomial / multinomial routines are templates over the generator of uniform doubles and compile for host and
+// device: with `Mt19937` on the host they ARE the bit-exact path above; with `Philox` (counter-based, below) one GPU
+// thread draws one multinomial row independently of every other row (`k_multinomial_rows`, opt-in
+// `sampler="device"`: same distribution, NOT the reference's stream).  Floating-point contraction is off in here:
+// every product and sum rounds as NumPy's build rounds it.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -21,9 +24,12 @@ namespace qt_sampler {
 
 #pragma clang fp contract(off)
 
+#define QT_SAMPLER_HD __host__ __device__
+
 struct Mt19937 {
   uint32_t* key;  // [624], updated in place
   int pos;        // 0..624 (624 = the block is used up)
+  inline uint32_t next();
 };
 
 inline void mt_refill(Mt19937& g) {
@@ -47,11 +53,49 @@ inline uint32_t mt_next(Mt19937& g) {
   return y;
 }
 
+inline uint32_t Mt19937::next() { return mt_next(*this); }
+
 // the legacy 53-bit double: 27 high bits of one word, 26 of the next
-inline double mt_double(Mt19937& g) {
-  const int32_t a = (int32_t)(mt_next(g) >> 5), b = (int32_t)(mt_next(g) >> 6);
+template <class G>
+QT_SAMPLER_HD inline double uniform53(G& g) {
+  const int32_t a = (int32_t)(g.next() >> 5), b = (int32_t)(g.next() >> 6);
   return (a * 67108864.0 + b) / 9007199254740992.0;
 }
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11): a keyed
+// bijection of a 128-bit counter, ten rounds of two 32x32 -> 64 multiplies.  A stream is (key = seed,
+// counter = {block index, row low, row high, substream}); it hands out the four words of a block in order.
+QT_SAMPLER_HD inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+struct Philox {
+  uint32_t key[2], ctr[4], word[4];
+  int have;
+  QT_SAMPLER_HD Philox(uint64_t seed, uint64_t row, uint32_t substream) : have(0) {
+    key[0] = (uint32_t)seed, key[1] = (uint32_t)(seed >> 32);
+    ctr[0] = 0, ctr[1] = (uint32_t)row, ctr[2] = (uint32_t)(row >> 32), ctr[3] = substream;
+  }
+  QT_SAMPLER_HD uint32_t next() {
+    if (have == 0) {
+      philox4x32_10(ctr, key, word);
+      ++ctr[0];  // 2^32 blocks per row: no binomial comes near
+      have = 4;
+    }
+    return word[4 - have--];
+  }
+};
 
 // The set-up constants of one (n, p): NumPy caches them in RandomState._binomial; they are pure functions of
 // (n, p), so a local cache gives the same draws.
@@ -69,7 +113,8 @@ struct BinomialSetup {
 };
 
 // n p <= 30: walk the mass function from 0 upwards; restart with a fresh uniform past `bound`
-inline int64_t binomial_inversion(Mt19937& g, int64_t n, double p, BinomialSetup& s) {
+template <class G>
+QT_SAMPLER_HD inline int64_t binomial_inversion(G& g, int64_t n, double p, BinomialSetup& s) {
   if (!s.valid || s.btpe || s.n != n || s.p != p) {
     s.valid = true, s.btpe = false, s.n = n, s.p = p;
     s.q = 1.0 - p;
@@ -81,13 +126,13 @@ inline int64_t binomial_inversion(Mt19937& g, int64_t n, double p, BinomialSetup
   const double q = s.q, qn = s.qn;
   const int64_t bound = s.bound;
   int64_t x = 0;
-  double px = qn, u = mt_double(g);
+  double px = qn, u = uniform53(g);
   while (u > px) {
     ++x;
     if (x > bound) {
       x = 0;
       px = qn;
-      u = mt_double(g);
+      u = uniform53(g);
     } else {
       u -= px;
       px = ((n - x + 1) * p * px) / (x * q);
@@ -98,7 +143,8 @@ inline int64_t binomial_inversion(Mt19937& g, int64_t n, double p, BinomialSetup
 
 // n p > 30 (p <= 0.5): BTPE -- triangle, parallelogram and two exponential tails as the envelope, then the
 // squeeze / exact acceptance tests of the published algorithm
-inline int64_t binomial_btpe(Mt19937& g, int64_t n, double p, BinomialSetup& s) {
+template <class G>
+QT_SAMPLER_HD inline int64_t binomial_btpe(G& g, int64_t n, double p, BinomialSetup& s) {
   if (!s.valid || !s.btpe || s.n != n || s.p != p) {
     s.valid = true, s.btpe = true, s.n = n, s.p = p;
     s.r = p < 1.0 - p ? p : 1.0 - p;
@@ -124,8 +170,8 @@ inline int64_t binomial_btpe(Mt19937& g, int64_t n, double p, BinomialSetup& s) 
   const double nrq = n * r * q;
   int64_t y;
   for (;;) {
-    const double u = mt_double(g) * p4;
-    double v = mt_double(g);
+    const double u = uniform53(g) * p4;
+    double v = uniform53(g);
     if (u <= p1) {  // triangle: accepted at once
       y = (int64_t)floor(xm - p1 * v + u);
       break;
@@ -175,7 +221,8 @@ inline int64_t binomial_btpe(Mt19937& g, int64_t n, double p, BinomialSetup& s) 
   return y;  // the caller only comes here with p <= 0.5: no reflection left to do
 }
 
-inline int64_t legacy_binomial(Mt19937& g, double p, int64_t n, BinomialSetup& s) {
+template <class G>
+QT_SAMPLER_HD inline int64_t legacy_binomial(G& g, double p, int64_t n, BinomialSetup& s) {
   if (n == 0 || p == 0.0) return 0;  // no word consumed (RandomState.multinomial shares random_binomial's early exit)
   if (p <= 0.5) return p * n <= 30.0 ? binomial_inversion(g, n, p, s) : binomial_btpe(g, n, p, s);
   const double q = 1.0 - p;
@@ -183,7 +230,8 @@ inline int64_t legacy_binomial(Mt19937& g, double p, int64_t n, BinomialSetup& s
 }
 
 // one RandomState.multinomial(n, pvals) row: conditional binomials, first to last-but-one category
-inline void legacy_multinomial(Mt19937& g, int64_t n, const double* pvals, int K, int64_t* out, BinomialSetup* cache) {
+template <class G>
+QT_SAMPLER_HD inline void legacy_multinomial(G& g, int64_t n, const double* pvals, int K, int64_t* out, BinomialSetup* cache) {
   double remaining_p = 1.0;
   int64_t dn = n;
   for (int j = 0; j < K; ++j) out[j] = 0;
@@ -194,6 +242,37 @@ inline void legacy_multinomial(Mt19937& g, int64_t n, const double* pvals, int K
     remaining_p -= pvals[j];
   }
   if (dn > 0) out[K - 1] = dn;
+}
+
+// Opt-in device sampler: row r (= resample r / period, setting r % period) is drawn by one thread from its own Philox
+// stream (seed, first_row + r), so the counts of a row depend on nothing but (seed, global row index, n, p): any
+// split of the rows over launches or ranks gives the same table.  The same conditional-binomial chain as above;
+// the rows of one setting sit `period` threads apart, neighbouring lanes work on different settings of one
+// resample (same n, similar p: mostly the same branch).  out is [rows][K] int64, what the estimators read.
+__global__ void __launch_bounds__(256) k_multinomial_rows(uint64_t seed, uint64_t first_row, long long rows, int period,
+                                                          const int64_t* __restrict__ n, const double* __restrict__ pvals,
+                                                          int K, int64_t* __restrict__ out) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int s = (int)((first_row + (uint64_t)r) % (uint64_t)period);
+  Philox g(seed, first_row + (uint64_t)r, 0u);
+  const double* p = pvals + (size_t)s * K;
+  int64_t* o = out + (size_t)r * K;
+  BinomialSetup setup;
+  double remaining_p = 1.0;
+  int64_t dn = n[s];
+  int j = 0;
+  for (; j < K - 1 && dn > 0; ++j) {
+    const double pj = p[j];
+    double pc = pj / remaining_p;  // rounding can leave it a hair above 1; a NaN must not reach the rejection loop
+    pc = pc >= 0.0 ? (pc <= 1.0 ? pc : 1.0) : 0.0;
+    const int64_t x = legacy_binomial(g, pc, dn, setup);
+    o[j] = x;
+    dn -= x;
+    remaining_p -= pj;
+  }
+  for (; j < K - 1; ++j) o[j] = 0;
+  o[K - 1] = dn > 0 ? dn : 0;
 }
 
 }  // namespace qt_sampler

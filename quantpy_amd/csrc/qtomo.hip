@@ -1196,11 +1196,25 @@ int qt_sorted_quantiles(qt_handle_t* h, const double* sorted, long long n, const
 }
 
 // ---- a4 / a12 / a16 host side: state.py:109-114, the draws of experiment() (qt_sampler.h) ---------
+static int check_pvals(int period, int K, const int64_t* n, const double* pvals);
+
 int qt_legacy_multinomial(uint32_t* mt_key, int* mt_pos, long long rows, int period, const int64_t* n,
                           const double* pvals, int K, int64_t* out) {
   if (!mt_key || !mt_pos || !n || !pvals || (rows > 0 && !out) || rows < 0 || period < 1 || K < 1)
     return fail(QT_ERR_ARG, "bad legacy_multinomial arguments");
   if (*mt_pos < 0 || *mt_pos > 624) return fail(QT_ERR_ARG, "MT19937 position %d outside 0..624", *mt_pos);
+  if (int r = check_pvals(period, K, n, pvals)) return r;
+  qt_sampler::Mt19937 g{mt_key, *mt_pos};
+  std::vector<qt_sampler::BinomialSetup> cache((size_t)period * K);
+  for (long long r = 0; r < rows; ++r) {
+    const int s = (int)(r % period);
+    qt_sampler::legacy_multinomial(g, n[s], pvals + (size_t)s * K, K, out + (size_t)r * K, cache.data() + (size_t)s * K);
+  }
+  *mt_pos = g.pos;
+  return 0;
+}
+
+static int check_pvals(int period, int K, const int64_t* n, const double* pvals) {
   for (int s = 0; s < period; ++s) {
     if (n[s] < 0) return fail(QT_ERR_ARG, "n < 0 in row %d", s);
     // RandomState.multinomial's own checks (mtrand.pyx): every pval in [0, 1], and the leading K - 1 may not exceed 1
@@ -1217,15 +1231,31 @@ int qt_legacy_multinomial(uint32_t* mt_key, int* mt_pos, long long rows, int per
     }
     if (head > 1.0 + 1e-12) return fail(QT_ERR_ARG, "sum(pvals[:-1]) > 1.0");
   }
-  qt_sampler::Mt19937 g{mt_key, *mt_pos};
-  std::vector<qt_sampler::BinomialSetup> cache((size_t)period * K);
-  for (long long r = 0; r < rows; ++r) {
-    const int s = (int)(r % period);
-    qt_sampler::legacy_multinomial(g, n[s], pvals + (size_t)s * K, K, out + (size_t)r * K, cache.data() + (size_t)s * K);
-  }
-  *mt_pos = g.pos;
   return 0;
 }
+
+int qt_device_multinomial(qt_handle_t* h, uint64_t seed, uint64_t first_row, long long rows, int period,
+                          const int64_t* n, const double* pvals, int K, int64_t* out, int flags) {
+  QT_ENTER(h);
+  if (!n || !pvals || (rows > 0 && !out) || rows < 0 || period < 1 || K < 1)
+    return fail(QT_ERR_ARG, "bad device_multinomial arguments");
+  if (rows > (1LL << 40)) return fail(QT_ERR_UNSUPPORTED, "qt_device_multinomial draws at most 2^40 rows per call");
+  if (!(flags & QT_DEVICE_PTR))
+    if (int r = check_pvals(period, K, n, pvals)) return r;
+  if (rows == 0) return 0;
+  const int64_t* dn;
+  const double* dp;
+  int64_t* dout;
+  if (int r = stage_in(h, h->in0, n, (size_t)period, flags, &dn)) return r;
+  if (int r = stage_in(h, h->in1, pvals, (size_t)period * K, flags, &dp)) return r;
+  if (int r = stage_out(h, h->out0, out, (size_t)rows * K, flags, &dout)) return r;
+  hipLaunchKernelGGL(qt_sampler::k_multinomial_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, seed,
+                     first_row, rows, period, dn, dp, K, dout);
+  if (int r = fetch_out(h, (const int64_t*)dout, out, (size_t)rows * K, flags)) return r;
+  return finish(h, flags);
+}
+
+void qt_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { qt_sampler::philox4x32_10(ctr, key, out); }
 
 // ---- a5 for arbitrary matrices: routines.py:69-71 -------------------------------------------------
 int qt_left_inverse(qt_handle_t* h, const double* A, int rows, int cols, int is_complex, double* out, int flags) {

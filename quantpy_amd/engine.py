@@ -467,6 +467,30 @@ class Engine:
         self._chk(self.lib.qt_hs_dist_dim(self._h, dim, _ptr(r), _ptr(centre), r.shape[0], _ptr(out), _capi.QT_HOST_PTR))
         return out[0] if single else out
 
+    def device_multinomial(self, n, pvals, rows, seed, first_row=0, out=None):
+        """`rows` multinomial draws made on the GPU (qt_device_multinomial): row r ~ multinomial(n[s], pvals[s]),
+        s = (first_row + r) % S, from the Philox stream (seed, first_row + r) -- the distribution of
+        `np.random.multinomial`, NOT its stream.  n (S,), pvals (S, K) on the host: counts (rows, K) int64 as a NumPy
+        array; `out` = an int64 torch CUDA tensor (rows, K): n / pvals may be CUDA tensors too, filled in stream order."""
+        if out is not None:
+            import torch
+
+            self._dev_call()
+            dev = out.device
+            n_d = n if _is_dev(n) else torch.as_tensor(np.ascontiguousarray(n, dtype=np.int64)).to(dev)
+            p_d = pvals if _is_dev(pvals) else torch.as_tensor(_f64(pvals)).to(dev)
+            assert out.dtype == torch.int64 and out.is_contiguous() and out.numel() == rows * p_d.shape[-1]
+            self._chk(self.lib.qt_device_multinomial(self._h, seed, first_row, rows, p_d.shape[0], _ptr(n_d), _ptr(p_d),
+                                                     p_d.shape[-1], _ptr(out), _capi.QT_DEVICE_PTR))
+            self._keep = (n_d, p_d)  # alive until the launch has read them
+            return out
+        n = np.ascontiguousarray(n, dtype=np.int64)
+        pvals = _f64(pvals)
+        counts = np.empty((rows, pvals.shape[-1]), dtype=np.int64)
+        self._chk(self.lib.qt_device_multinomial(self._h, seed, first_row, rows, pvals.shape[0], _ptr(n), _ptr(pvals),
+                                                 pvals.shape[-1], _ptr(counts), _capi.QT_HOST_PTR))
+        return counts
+
     def hs_dist_dev(self, rho, centre, out):
         self._dev_call()
         self._chk(self.lib.qt_hs_dist_batch(self._h, _ptr(rho), _ptr(centre), rho.shape[0], _ptr(out),

@@ -6,6 +6,10 @@ same order, same bits, and `np.random`'s state afterwards is what the reference'
 call of `qt_legacy_multinomial` (csrc/qt_sampler.h), which restates NumPy's legacy sampler in C and advances the
 MT19937 state of the global `RandomState` in place (through the address NumPy's own `BitGenerator.ctypes` interface
 publishes, under the generator's lock).
+
+`device_multinomial` is the opt-in alternative for callers that need the distribution but not the reference's stream
+(`sampler="device"` on `experiment` / `experiment_batch` / the bootstrap intervals): the draws are made on the GPU
+(`qt_device_multinomial`, one Philox stream per row), which takes the sampler out of a bootstrap's critical path.
 """
 import ctypes
 
@@ -83,3 +87,48 @@ def legacy_multinomial(n, pvals, repeats=1):
     if rc < 0:
         raise ValueError(_capi.last_error())  # NumPy raises ValueError for the same conditions
     return out
+
+
+SAMPLERS = ("numpy", "device")
+
+
+def device_multinomial(n, pvals, repeats=1, seed=None, engine=None):
+    """The table `legacy_multinomial` returns, in distribution: int64 (repeats, S, K) with row (r, s) ~
+    multinomial(n[s], pvals[s]), drawn on the GPU from the Philox stream (seed, r * S + s).  seed=None takes 64 bits
+    from `np.random`'s global stream (so `np.random.seed` still makes a run reproducible); the counts are NOT those
+    of the reference for that seed."""
+    pvals = np.ascontiguousarray(pvals, dtype=np.float64)
+    if pvals.ndim != 2:
+        raise ValueError("pvals must be (settings, outcomes)")
+    n_set, n_out = pvals.shape
+    n = np.ascontiguousarray(np.asarray(n).astype(np.int64))
+    if n.shape != (n_set,):
+        raise ValueError("one `n` per row of pvals")
+    if seed is None:
+        lo, hi = (int(w) for w in np.random.randint(0, 2**32, size=2, dtype=np.uint64))
+        seed = lo | (hi << 32)
+    if engine is None:
+        from .engine import get_engine
+
+        engine = get_engine(1)
+    from .engine import EngineError
+
+    try:
+        counts = engine.device_multinomial(n, pvals, repeats * n_set, int(seed) & (2**64 - 1))
+    except EngineError as err:
+        if err.code == _capi.QT_ERR_ARG:
+            raise ValueError(_capi.last_error()) from None
+        raise
+    return counts.reshape(repeats, n_set, n_out)
+
+
+def draw_counts(n, pvals, repeats=1, sampler="numpy", seed=None):
+    """One entry for both samplers: 'numpy' = the reference's stream bit for bit (seed must be None: the stream is
+    `np.random`'s), 'device' = the GPU sampler."""
+    if sampler == "numpy":
+        if seed is not None:
+            raise ValueError("sampler='numpy' draws from np.random's global stream: seed it with np.random.seed")
+        return legacy_multinomial(n, pvals, repeats)
+    if sampler == "device":
+        return device_multinomial(n, pvals, repeats, seed)
+    raise ValueError(f"sampler must be one of {SAMPLERS}, not {sampler!r}")

@@ -146,7 +146,7 @@ class BootstrapStateInterval(ConfidenceInterval):
     tomograph's own POVM and shots; distances tmg.dst(resampled estimate, state)."""
 
     def __init__(self, tmg, n_points=1000, method="lin", physical=True, init="lin", tol=1e-3, max_iter=100,
-                 state=None):
+                 state=None, sampler="numpy", seed=None):
         super().__init__(tmg, **_pop_hidden_keys(locals()))
 
     def setup(self):
@@ -162,7 +162,9 @@ class BootstrapStateInterval(ConfidenceInterval):
         boot = tmg.__class__(self.state, tmg.dst)
         # every resample's counts, one global RNG stream in the reference's order (resample after resample, setting
         # after setting): ONE call of the C restatement of NumPy's sampler instead of n_points x S Python calls
-        counts = boot.experiment_batch(tmg.n_measurements, tmg.povm_matrix, self.n_points)
+        # (sampler='device', opt-in: the same distribution drawn on the GPU, off the reference's stream)
+        counts = boot.experiment_batch(tmg.n_measurements, tmg.povm_matrix, self.n_points, sampler=self.sampler,
+                                       seed=self.seed)
         counts = qdist.broadcast_array(counts) if self.n_points else np.empty((0,) + tmg.results.shape)
         self.boot_counts = counts
         centre = self.state
@@ -387,7 +389,7 @@ class BootstrapProcessInterval(ConfidenceInterval):
     channel): resampled counts for every input state, batched Choi reconstruction."""
 
     def __init__(self, tmg, n_points=1000, method="lifp", cptp=True, tol=1e-10, channel=None,
-                 states_est_method="lin", states_physical=True, states_init="lin"):
+                 states_est_method="lin", states_physical=True, states_init="lin", sampler="numpy", seed=None):
         super().__init__(tmg, **_pop_hidden_keys(locals()))
 
     def setup(self):
@@ -402,7 +404,8 @@ class BootstrapProcessInterval(ConfidenceInterval):
                                                   states_init=self.states_init, cptp=self.cptp)
         boot = tmg.__class__(self.channel, tmg.input_states, tmg.dst)
         shots, povm = tmg.tomographs[0].n_measurements, tmg.tomographs[0].povm_matrix
-        counts = qdist.broadcast_array(boot.experiment_batch(shots, povm=povm, repeats=self.n_points))
+        counts = qdist.broadcast_array(boot.experiment_batch(shots, povm=povm, repeats=self.n_points,
+                                                             sampler=self.sampler, seed=self.seed))
         self.boot_counts = counts
         centre = self.channel.choi
 

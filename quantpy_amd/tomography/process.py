@@ -14,7 +14,7 @@ from ..engine import get_engine
 from ..measurements import generate_measurement_matrix
 from ..qobj import Qobj
 from ..routines import _mat2vec, _out_ptrace_oper, _vec2mat, generate_single_entries
-from ..sampling import legacy_multinomial
+from ..sampling import draw_counts
 from .state import StateTomograph, _resolve_dst, born_probabilities
 
 
@@ -54,14 +54,16 @@ class ProcessTomograph:
         self._ptrace_dag_ptrace = self._ptrace_oper.T.conj() @ self._ptrace_oper
 
     # ---- data -------------------------------------------------------------------------------------
-    def experiment(self, n_measurements, povm="proj-set", warm_start=False):
-        """State tomography of channel(rho_in) for every input state, in basis order."""
+    def experiment(self, n_measurements, povm="proj-set", warm_start=False, sampler="numpy", seed=None):
+        """State tomography of channel(rho_in) for every input state, in basis order.  sampler='device' (opt-in, see
+        StateTomograph.experiment): input state i draws from the Philox streams of seed + i."""
         if not warm_start:
             self.tomographs = [StateTomograph(self.channel.transform(state)) for state in self.input_basis.elements]
-        for tmg in self.tomographs:
-            tmg.experiment(n_measurements, povm, warm_start=warm_start)
+        for i, tmg in enumerate(self.tomographs):
+            tmg.experiment(n_measurements, povm, warm_start=warm_start, sampler=sampler,
+                           seed=None if seed is None else int(seed) + i)
 
-    def experiment_batch(self, n_measurements, povm="proj-set", repeats=1):
+    def experiment_batch(self, n_measurements, povm="proj-set", repeats=1, sampler="numpy", seed=None):
         """Counts (repeats, n_inputs, S, K) of `repeats` successive `experiment(n_measurements, povm)` calls, drawn in
         one call in the same order on the same global stream (resample, input state, setting: the loop of reference
         interval.py:673-676).  Leaves the tomographs as the last of those calls would."""
@@ -70,7 +72,7 @@ class ProcessTomograph:
         povm_matrix, shots = first._experiment_arguments(n_measurements, povm)
         probas = np.concatenate([born_probabilities(povm_matrix, tmg.state.bloch) for tmg in self.tomographs])
         n_in, n_set = len(self.tomographs), povm_matrix.shape[0]
-        counts = legacy_multinomial(np.tile(shots, n_in), probas, repeats).reshape(repeats, n_in, n_set, -1)
+        counts = draw_counts(np.tile(shots, n_in), probas, repeats, sampler, seed).reshape(repeats, n_in, n_set, -1)
         if repeats:
             for tmg, last in zip(self.tomographs, counts[-1]):
                 tmg.povm_matrix, tmg.results, tmg.n_measurements = povm_matrix, last, np.asarray(shots)

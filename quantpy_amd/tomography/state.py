@@ -11,7 +11,7 @@ from ..engine import get_engine
 from ..geometry import hs_dst, if_dst, trace_dst
 from ..measurements import generate_measurement_matrix
 from ..qobj import Qobj
-from ..sampling import legacy_multinomial
+from ..sampling import draw_counts
 
 _DISTANCES = {"hs": hs_dst, "trace": trace_dst, "if": if_dst}
 
@@ -34,12 +34,15 @@ def born_probabilities(povm_matrix, bloch):
     return np.clip(probas, 0, 1)
 
 
-def simulate_counts(povm_matrix, bloch, n_measurements, repeats=None):
+def simulate_counts(povm_matrix, bloch, n_measurements, repeats=None, sampler="numpy", seed=None):
     """Born probabilities + multinomial draws for one state (reference state.py:109-114): one draw per POVM setting,
     in order, on NumPy's global legacy stream -- made by `qt_legacy_multinomial`, which restates NumPy's sampler bit
     for bit, so a seed reproduces the reference's counts and leaves `np.random` where the reference leaves it.
-    `repeats=R` gives the (R, S, K) counts of R successive experiments (a bootstrap's resamples) from one call."""
-    counts = legacy_multinomial(n_measurements, born_probabilities(povm_matrix, bloch), 1 if repeats is None else repeats)
+    `repeats=R` gives the (R, S, K) counts of R successive experiments (a bootstrap's resamples) from one call.
+    sampler='device' (opt-in): the same distribution drawn on the GPU from Philox streams keyed by `seed`
+    (sampling.device_multinomial) -- not the reference's counts for a given np.random.seed."""
+    counts = draw_counts(n_measurements, born_probabilities(povm_matrix, bloch), 1 if repeats is None else repeats,
+                         sampler, seed)
     return counts[0] if repeats is None else counts
 
 
@@ -70,16 +73,17 @@ class StateTomograph:
             raise ValueError("Wrong length for argument `n_measurements`")
         return povm_matrix, n_measurements
 
-    def experiment(self, n_measurements, povm="proj-set", warm_start=False):
+    def experiment(self, n_measurements, povm="proj-set", warm_start=False, sampler="numpy", seed=None):
         """Draw measurement outcomes.
 
         n_measurements : integer (shots per POVM setting) or one entry per setting.  A float
             scalar is rejected exactly like the reference does (TypeError from len()).
         povm : name or array, see `generate_measurement_matrix`.
         warm_start : append to the data of the previous call instead of replacing it.
+        sampler, seed : 'numpy' (default) = the reference's draws on np.random's stream; 'device' = GPU sampler.
         """
         povm_matrix, n_measurements = self._experiment_arguments(n_measurements, povm)
-        counts = simulate_counts(povm_matrix, self.state.bloch, n_measurements)
+        counts = simulate_counts(povm_matrix, self.state.bloch, n_measurements, sampler=sampler, seed=seed)
         if warm_start:
             old_total, new_total = np.sum(self.n_measurements), np.sum(n_measurements)
             self.povm_matrix = np.vstack((self.povm_matrix * old_total, povm_matrix * new_total)) / (old_total + new_total)
@@ -89,12 +93,12 @@ class StateTomograph:
             self.results = counts
             self.n_measurements = np.asarray(n_measurements)
 
-    def experiment_batch(self, n_measurements, povm="proj-set", repeats=1):
+    def experiment_batch(self, n_measurements, povm="proj-set", repeats=1, sampler="numpy", seed=None):
         """The counts (repeats, S, K) of `repeats` successive `experiment(n_measurements, povm)` calls -- same global
         stream, same order -- drawn in one call (the resampling loop of a bootstrap, reference interval.py:598-604).
         Leaves the tomograph as the last of those calls would."""
         povm_matrix, n_measurements = self._experiment_arguments(n_measurements, povm)
-        counts = simulate_counts(povm_matrix, self.state.bloch, n_measurements, repeats=repeats)
+        counts = simulate_counts(povm_matrix, self.state.bloch, n_measurements, repeats=repeats, sampler=sampler, seed=seed)
         if repeats:
             self.povm_matrix = povm_matrix
             self.results = counts[-1]

@@ -43,3 +43,15 @@ for n_points in (200, 2000):
     print(f"n_points={n_points}: setup() {1e3 * (t1 - t0):8.2f} ms   of which resampling (one qt_legacy_multinomial call) "
           f"{1e3 * (t3 - t2):7.2f} ms [per-resample experiment() loop: {1e3 * (t7 - t6):7.1f} ms], "
           f"batched mle incl. H2D/D2H {1e3 * (t5 - t4):6.2f} ms;  radii {iv([0.5, 0.9, 0.95])[0]}", flush=True)
+    # opt-in: the resamples drawn on the GPU (qt_device_multinomial) -- same distribution, not the reference's stream
+    for rep in range(3):
+        t8 = time.perf_counter()
+        dv = qp.BootstrapStateInterval(tmg, n_points=n_points, method="mle", sampler="device", seed=rep)
+        dv.setup()
+        t9 = time.perf_counter()
+    t10 = time.perf_counter()
+    boot.experiment_batch(tmg.n_measurements, tmg.povm_matrix, n_points, sampler="device", seed=1)
+    t11 = time.perf_counter()
+    print(f"n_points={n_points}: sampler='device': setup() {1e3 * (t9 - t8):8.2f} ms   of which resampling "
+          f"(Born probabilities on the host + qt_device_multinomial + D2H) {1e3 * (t11 - t10):7.2f} ms;  "
+          f"radii {dv([0.5, 0.9, 0.95])[0]}", flush=True)

@@ -427,3 +427,21 @@ def test_c_sampler_argument_errors_are_codes_not_crashes():
     pos.value = 0
     n[0] = -3
     assert lib.qt_legacy_multinomial(*ok) == -1
+
+
+def test_philox4x32_10_known_answers():
+    """The block function of the opt-in device sampler (csrc/qt_sampler.h) against the known-answer vectors published
+    with the algorithm (Random123 kat_vectors, philox4x32 with 10 rounds): zero, all-ones and the digits of pi."""
+    from quantpy_amd import _capi
+
+    lib = _capi.load()
+    cases = [
+        ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+        ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+        ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+    ]
+    for ctr, key, want in cases:
+        c, k, out = np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+        lib.qt_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+        assert out.tolist() == want, [hex(v) for v in out]

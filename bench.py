@@ -564,6 +564,25 @@ def main():
         # resample), drawn by qt_legacy_multinomial in one call -- serial by nature, the same on every rank
         boot["resampling_host_ms"] = round(sample_ms, 3)
         boot["resampling"] = "qt_legacy_multinomial: np.random's MT19937 stream, reference call order, bit-exact"
+        # opt-in alternative (sampler='device'): this rank's shard of the resamples drawn in HBM by qt_device_multinomial
+        # (one Philox stream per row: the table does not depend on the number of ranks); same distribution, other stream
+        from quantpy_amd.tomography.state import born_probabilities
+
+        lo_b, hi_b = qd.shard_bounds(args.bootstrap_points)
+        n_set_b = povm.shape[0]
+        dev_counts = torch.empty(((hi_b - lo_b) * n_set_b, povm.shape[1]), dtype=torch.int64, device="cuda")
+        p_d = torch.from_numpy(born_probabilities(povm, centre.bloch)).cuda()
+        n_d = torch.from_numpy(np.asarray(tmg.n_measurements).astype(np.int64)).cuda()
+        draw = lambda: eng.device_multinomial(n_d, p_d, (hi_b - lo_b) * n_set_b, 4242, first_row=lo_b * n_set_b, out=dev_counts)
+        draw()
+        eng.sync()
+        ts = time.perf_counter()
+        for _ in range(5):
+            draw()
+        eng.sync()
+        boot["resampling_device_ms"] = round(max_over_ranks((time.perf_counter() - ts) * 1e3 / 5), 4)
+        assert bool((dev_counts.sum(1) == n_d.repeat(hi_b - lo_b)).all())
+        del dev_counts
         if args.bootstrap_large > 0:
             distinct = min(args.bootstrap_large, 32768)
             pool = vector_resamples(povm, centre.bloch, tmg.n_measurements, distinct, 99)

@@ -192,7 +192,7 @@ int qt_mhmc_state(qt_handle_t* h, const int64_t* counts, int C, const double* x_
 
 /* ---- a11-a15: quantpy/tomography/process.py -------------------------------------------------- */
 /* Process tomography of an n-qubit channel (handle created with n_qubits = n; n <= 3: 'lifp', the projections and
- * what builds on them ('states', the bootstrap); 'pgdb' and the process chain n <= 2).
+ * what builds on them ('states', the bootstrap) and 'pgdb'; the process chain n <= 2).
  * qt_process_setup: input states in_states[D][d][d][2] (process.py:79), the weighted POVM of
  * qt_set_povm (call it first) -> design matrix rows vec(rho_in (x) E_m^T) (process.py:203-208),
  * its left inverse (process.py:210), and the partial-trace operator (routines.py:47-50). */
@@ -215,6 +215,13 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
  * decrease falls below tol.  iters[B], status[B] nullable. */
 int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, double tol, int stop_rule, double* choi,
                   int32_t* iters, int32_t* status, int flags);
+/* The pieces of ONE 'pgdb' iteration at the points choi_in[B][D][D][2] (process.py:296-298), for checking the
+ * factored n = 3 operators against the reference's dense ones: probas[B][D*M] = Re(L c), grad[B][D][D][2] =
+ * -L^H (n / p) laid out like the Choi matrix (entry [i][j] = component j D + i of the reference's column-stacked
+ * vector), projected[B][D][D][2] = P_CPTP(c - grad / mu).  Each output nullable.  n = 3 only (n <= 2 keeps the whole
+ * loop in one kernel, tested through its results). */
+int qt_pgdb_pieces(qt_handle_t* h, const int64_t* counts, int B, const double* choi_in, double* probas, double* grad,
+                   double* projected, int flags);
 /* Metropolis-Hastings chains on the Choi vector (MHMCProcessInterval, interval.py:808-836): proposals
  * P_CPTP(x + step * delta), target exp(-nll) with the raw counts.  counts[C][D][S][K], choi_init[C][D][D][2],
  * deltas[C][T][D*D] (real, indexed like the column-stacked Choi vector), uniforms[C][T];

@@ -59,6 +59,7 @@ SIGNATURES = {
     "qt_device_multinomial": (_c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp,
                                        _c_int]),
     "qt_philox4x32_10": (None, [_vp, _vp, _vp]),
+    "qt_pgdb_pieces": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int]),
     "qt_process_setup": (_c_int, [_vp, _vp, _c_int]),
     "qt_process_get_operators": (_c_int, [_vp, _vp, _vp, _c_int]),
     "qt_process_get_factors": (_c_int, [_vp, _vp, _vp, _c_int]),

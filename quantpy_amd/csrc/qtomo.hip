@@ -1484,7 +1484,6 @@ int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, doub
   if (B < 0 || (B > 0 && (!counts || !choi))) return fail(QT_ERR_ARG, "bad pgdb_batch arguments");
   if (stop_rule != 0 && stop_rule != 1) return fail(QT_ERR_ARG, "stop_rule must be 0 (reference) or 1 (converged)");
   if (n_iter < 0) return fail(QT_ERR_ARG, "n_iter must be >= 0");
-  if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "'pgdb' supports n_qubits 1..2 in this release ('lifp' and 'states': 1..3)");
   if (B == 0) return 0;
   const int D = h->D, M = h->M;
   const int64_t* dc;
@@ -1494,6 +1493,42 @@ int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, doub
   if (int r = stage_out(h, h->out0, choi, (size_t)B * D * D * 2, flags, &dchoi)) return r;
   if (int r = stage_out(h, h->out1, iters, (size_t)B, flags, &dit)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
+  if (h->proc.factored) {  // n = 3: three launches per iteration over the batch, loop state on the device (qt_process64.h)
+    using S = qt::Pgdb64;
+    const size_t ne2 = (size_t)D * D * 2;
+    HIPCHK(h->ws_x.ensure((size_t)B * S::ws_doubles(M) * sizeof(double)));
+    HIPCHK(h->ws_g.ensure((size_t)B * ne2 * sizeof(double)));  // trial points c - g / mu
+    HIPCHK(h->ws_f.ensure((size_t)B * ne2 * sizeof(double)));  // their CPTP projections
+    HIPCHK(h->proc_ws.ensure((size_t)B * qt::Proc64::kWsComplex * 2 * sizeof(double)));
+    HIPCHK(h->ws_act.ensure(((size_t)B * 4 + 4) * sizeof(int32_t)));
+    int32_t* state = h->ws_act.as<int32_t>();
+    int32_t* n_active = state + (size_t)B * 4;
+    if (int r = allow_big_lds(qt::k_cptp_project64, qt::Proc64::kLdsBytes)) return r;
+    if (int r = allow_big_lds(qt::k_pgdb64_grad, S::kLdsBytes)) return r;
+    if (int r = allow_big_lds(qt::k_pgdb64_step, S::kLdsBytes)) return r;
+    const double *vs = (const double*)h->proc.in_states, *vp = (const double*)h->proc.emats;
+    hipLaunchKernelGGL(qt::k_pgdb64_init, dim3(B), dim3(256), 0, h->stream, B, dchoi, state, dit, dst, n_active);
+    for (int it = 0; it < n_iter; ++it) {
+      hipLaunchKernelGGL(qt::k_pgdb64_grad, dim3(B), dim3(S::NT), S::kLdsBytes, h->stream, dc, B, M, vs, vp, (const double*)dchoi,
+                         (const int32_t*)state, h->ws_x.as<double>(), h->ws_g.as<double>());
+      hipLaunchKernelGGL(qt::k_cptp_project64, dim3(B), dim3(qt::Proc64::NT), qt::Proc64::kLdsBytes, h->stream,
+                         (const double*)h->ws_g.as<double>(), B, 0, 1000, 1e-12, h->ws_f.as<double>(), (int32_t*)nullptr,
+                         (int32_t*)nullptr, h->proc_ws.as<double>());
+      hipLaunchKernelGGL(qt::k_pgdb64_step, dim3(B), dim3(S::NT), S::kLdsBytes, h->stream, dc, B, M, vs, vp,
+                         (const double*)h->ws_f.as<double>(), n_iter, tol, stop_rule, dchoi, state, h->ws_x.as<double>(), dit, dst,
+                         n_active);
+      int left = 0;
+      HIPCHK(hipMemcpyAsync(&left, n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      QT_STREAM_SYNC(h);
+      if (left <= 0) break;
+    }
+    HIPCHK(hipGetLastError());
+    if (int r = fetch_out(h, dchoi, choi, (size_t)B * D * D * 2, flags)) return r;
+    if (int r = fetch_out(h, dit, iters, (size_t)B, flags)) return r;
+    if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
+    if (int r = finish(h, flags)) return r;
+    return count_bad(status, B, flags);
+  }
   const size_t dyn = (size_t)4 * D * M * sizeof(double);
   if (dyn > 32 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the process kernel");
   if (D == 4)
@@ -1507,6 +1542,47 @@ int qt_pgdb_batch(qt_handle_t* h, const int64_t* counts, int B, int n_iter, doub
   if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
   if (int r = finish(h, flags)) return r;
   return count_bad(status, B, flags);
+}
+
+int qt_pgdb_pieces(qt_handle_t* h, const int64_t* counts, int B, const double* choi_in, double* probas, double* grad,
+                   double* projected, int flags) {
+  QT_ENTER(h);
+  if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
+  if (B < 0 || (B > 0 && (!counts || !choi_in))) return fail(QT_ERR_ARG, "bad pgdb_pieces arguments");
+  if (!h->proc.factored) return fail(QT_ERR_UNSUPPORTED, "qt_pgdb_pieces inspects the factored (n = 3) iteration");
+  if (B == 0) return 0;
+  using S = qt::Pgdb64;
+  const int D = h->D, M = h->M, R = D * M;
+  const size_t ne2 = (size_t)D * D * 2, wsd = S::ws_doubles(M);
+  const int64_t* dc;
+  const double* dcur;
+  if (int r = stage_in(h, h->in0, counts, (size_t)B * R, flags, &dc)) return r;
+  if (int r = stage_in(h, h->in1, choi_in, (size_t)B * ne2, flags, &dcur)) return r;
+  HIPCHK(h->ws_x.ensure((size_t)B * wsd * sizeof(double)));
+  HIPCHK(h->ws_g.ensure((size_t)B * ne2 * sizeof(double)));
+  HIPCHK(h->ws_f.ensure((size_t)B * ne2 * sizeof(double)));
+  HIPCHK(h->proc_ws.ensure((size_t)B * qt::Proc64::kWsComplex * 2 * sizeof(double)));
+  HIPCHK(h->ws_act.ensure(((size_t)B * 4 + 4) * sizeof(int32_t)));
+  int32_t* state = h->ws_act.as<int32_t>();
+  HIPCHK(hipMemsetAsync(state, 0, ((size_t)B * 4 + 4) * sizeof(int32_t), h->stream));
+  if (int r = allow_big_lds(qt::k_cptp_project64, qt::Proc64::kLdsBytes)) return r;
+  if (int r = allow_big_lds(qt::k_pgdb64_grad, S::kLdsBytes)) return r;
+  hipLaunchKernelGGL(qt::k_pgdb64_grad, dim3(B), dim3(S::NT), S::kLdsBytes, h->stream, dc, B, M, (const double*)h->proc.in_states,
+                     (const double*)h->proc.emats, dcur, (const int32_t*)state, h->ws_x.as<double>(), h->ws_g.as<double>());
+  hipLaunchKernelGGL(qt::k_cptp_project64, dim3(B), dim3(qt::Proc64::NT), qt::Proc64::kLdsBytes, h->stream,
+                     (const double*)h->ws_g.as<double>(), B, 0, 1000, 1e-12, h->ws_f.as<double>(), (int32_t*)nullptr,
+                     (int32_t*)nullptr, h->proc_ws.as<double>());
+  HIPCHK(hipGetLastError());
+  const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  const double* ws = h->ws_x.as<double>();
+  if (probas)
+    HIPCHK(hipMemcpy2DAsync(probas, (size_t)R * sizeof(double), ws + (size_t)2 * D * M, wsd * sizeof(double),
+                            (size_t)R * sizeof(double), B, kind, h->stream));
+  if (grad)
+    HIPCHK(hipMemcpy2DAsync(grad, ne2 * sizeof(double), ws + (size_t)2 * D * M + 3 * (size_t)R, wsd * sizeof(double),
+                            ne2 * sizeof(double), B, kind, h->stream));
+  if (projected) HIPCHK(hipMemcpyAsync(projected, h->ws_f.p, (size_t)B * ne2 * sizeof(double), kind, h->stream));
+  return finish(h, flags);
 }
 
 int qt_mhmc_process(qt_handle_t* h, const int64_t* counts, int C, const double* choi_init, const double* deltas,

@@ -292,6 +292,17 @@ class Engine:
             choi, iters = choi[0], iters[0]
         return (choi, iters) if return_iters else choi
 
+    def pgdb_pieces(self, counts, choi):
+        """One 'pgdb' iteration's pieces at `choi` (n = 3, qt_pgdb_pieces): (probas (D*M,), grad (D, D) laid out like
+        the Choi matrix, P_CPTP(choi - grad / mu) (D, D))."""
+        c = _i64(counts).reshape(1, self.D, self.S, self.K)
+        x = _c128(choi).reshape(1, self.D, self.D)
+        probas = np.empty((1, c[0].size))
+        grad = np.empty((1, self.D, self.D), dtype=np.complex128)
+        proj = np.empty((1, self.D, self.D), dtype=np.complex128)
+        self._chk(self.lib.qt_pgdb_pieces(self._h, _ptr(c), 1, _ptr(x), _ptr(probas), _ptr(grad), _ptr(proj), _capi.QT_HOST_PTR))
+        return probas[0], grad[0], proj[0]
+
     def mhmc_process(self, counts, choi_init, deltas, uniforms, step):
         """Metropolis-Hastings chain of MHMCProcessInterval: counts (D, S, K), choi_init (D, D), deltas
         (T, D*D) real (column-stacked index), uniforms (T,) -> (chain (T, D, D) complex, accepted (T,))."""

@@ -889,9 +889,58 @@ def gen_leftovers():
     save("leftovers", **out)
 
 
+# --------------------------------------------------------------------------------------
+# (f) 'pgdb' at n = 3 (process.py:291-314 is size-generic): what the reference returns on the Q0 data of
+# gen_process3, and its loop with the step accepted (the evident intent), three iterations, piece by piece
+# --------------------------------------------------------------------------------------
+def gen_pgdb3():
+    import time as _time
+    from quantpy.routines import _mat2vec, _vec2mat
+    from quantpy.qobj import fully_mixed
+
+    out = {}
+    t0 = _time.time()
+    np.random.seed(31)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 3))
+    tmg.experiment(10000, "proj-set")
+    out["R0_counts"] = tmg.results
+    out["R0_input_states"] = np.stack([s_.matrix for s_ in tmg.input_basis.elements])
+    ch = tmg.point_estimate("pgdb", n_iter=2)  # the reference as it is (leaves in its first iteration)
+    out["R0_returned"] = ch.choi.matrix
+    print(f"   reference pgdb(n_iter=2): {_time.time() - t0:.0f} s; returned == start: "
+          f"{np.allclose(ch.choi.matrix, fully_mixed(6).matrix)}")
+    v = _mat2vec(fully_mixed(6).matrix)
+    mu, gamma, tol, cap = 1.5 / 4**3, 0.3, 1e-10, 3
+    trace, iterates = [], []
+    for it in range(cap):
+        probas = tmg._lifp_oper @ v
+        grad = -tmg._lifp_oper.T.conj() @ (tmg._unnorm_results / probas)
+        direction = tmg._cptp_projection_vec(v - grad / mu) - v
+        alpha = 1
+        while tmg._nll(v + alpha * direction) - tmg._nll(v) > gamma * alpha * np.dot(direction, grad):
+            alpha /= 2
+        if it == 0:
+            out["R0_it0_probas"] = probas
+            out["R0_it0_grad"] = grad
+            out["R0_it0_direction"] = direction
+            out["R0_it0_dot"] = np.array(np.dot(direction, grad))
+        new = v + alpha * direction
+        f0, f1 = tmg._nll(v), tmg._nll(new)
+        trace.append([f0, f1, alpha])
+        v = new
+        iterates.append(_vec2mat(v).copy())
+        print(f"   step {it}: nll {np.real(f0):.6f} -> {np.real(f1):.6f}, alpha {alpha}  ({_time.time() - t0:.0f} s)")
+        if not (f0 - f1 > tol):
+            break
+    out["R0_conv_cap"] = np.array(cap)
+    out["R0_conv_iterates"] = np.stack(iterates)
+    out["R0_conv_trace"] = np.array(trace)
+    save("pgdb3", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large",
-                             "pgdb", "constr", "mhmc", "holder", "leftovers", "process3"]
+                             "pgdb", "constr", "mhmc", "holder", "leftovers", "process3", "pgdb3"]
     table = {
         "operators": gen_operators,
         "states": gen_states_and_born,
@@ -904,6 +953,7 @@ if __name__ == "__main__":
         "bootstrap": gen_bootstrap,
         "large": gen_large,
         "pgdb": gen_pgdb,
+        "pgdb3": gen_pgdb3,
         "constr": gen_constr,
         "mhmc": gen_mhmc,
         "holder": gen_holder,

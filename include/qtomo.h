@@ -192,7 +192,8 @@ int qt_mhmc_state(qt_handle_t* h, const int64_t* counts, int C, const double* x_
 
 /* ---- a11-a15: quantpy/tomography/process.py -------------------------------------------------- */
 /* Process tomography of an n-qubit channel (handle created with n_qubits = n; n <= 3: 'lifp', the projections and
- * what builds on them ('states', the bootstrap) and 'pgdb'; the process chain n <= 2).
+ * what builds on them ('states', the bootstrap), 'pgdb' and the process chain all run for n <= 3; at n = 3 through the
+ * Kronecker factors of the design matrix).
  * qt_process_setup: input states in_states[D][d][d][2] (process.py:79), the weighted POVM of
  * qt_set_povm (call it first) -> design matrix rows vec(rho_in (x) E_m^T) (process.py:203-208),
  * its left inverse (process.py:210), and the partial-trace operator (routines.py:47-50). */

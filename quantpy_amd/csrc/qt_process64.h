@@ -722,4 +722,65 @@ __global__ void __launch_bounds__(Pgdb64::NT) k_pgdb64_step(const int64_t* __res
   }
 }
 
+// The Metropolis-Hastings chain of MHMCProcessInterval at n = 3 (interval.py:808-836; the arithmetic as k_mhmc_process
+// restates it for n <= 2): step t proposes x' = P_CPTP(x + step * delta_t) and accepts iff u_t <= exp(nll(x) - nll(x')),
+// nll = -sum n log|L x + 1e-12| with L applied through its factors (Pgdb64::forward).  Three launches per step --
+// k_mhmc64_propose, k_cptp_project64, k_mhmc64_accept -- with the chain's point and its NLL in global memory; nothing
+// returns to the host between steps.  t = -1 evaluates the NLL of the starting point.
+__global__ void __launch_bounds__(256) k_mhmc64_propose(int C, int T_steps, int t, double step, const double* __restrict__ x,
+                                                        const double* __restrict__ deltas, double* __restrict__ trial) {
+  const int c = blockIdx.x;
+  if (c >= C) return;
+  const cd* cur = reinterpret_cast<const cd*>(x) + (size_t)c * Pgdb64::NE;
+  cd* out = reinterpret_cast<cd*>(trial) + (size_t)c * Pgdb64::NE;
+  const double* dl = deltas + ((size_t)c * T_steps + t) * Pgdb64::NE;
+  for (int k = threadIdx.x; k < Pgdb64::NE; k += 256) {
+    const int row = k >> 6, col = k & 63;
+    out[k] = cd{cur[k].re + step * dl[col * Pgdb64::DC + row], cur[k].im};  // delta is indexed like the column-stacked vector
+  }
+}
+
+__global__ void __launch_bounds__(Pgdb64::NT) k_mhmc64_accept(const int64_t* __restrict__ counts, int C, int M, int T_steps, int t,
+                                                             const double* __restrict__ vs, const double* __restrict__ vp,
+                                                             const double* __restrict__ proposal,
+                                                             const double* __restrict__ uniforms, double* __restrict__ x,
+                                                             double* __restrict__ fcur, double* __restrict__ ws,
+                                                             double* __restrict__ chain_out, int32_t* __restrict__ accepted) {
+  extern __shared__ __attribute__((aligned(16))) double smp[];
+  const int c = blockIdx.x;
+  if (c >= C) return;
+  using S = Pgdb64;
+  const int R = S::DC * M;
+  cd* X = reinterpret_cast<cd*>(smp);
+  double* red = smp + 2 * S::DC * S::P;
+  double* wsb = ws + (size_t)c * S::ws_doubles(M);
+  cd* Y = reinterpret_cast<cd*>(wsb);
+  double* p = wsb + (size_t)2 * S::DC * M;
+  cd* cur = reinterpret_cast<cd*>(x) + (size_t)c * S::NE;
+  const cd* prop = t < 0 ? cur : reinterpret_cast<const cd*>(proposal) + (size_t)c * S::NE;
+  S::load_x(prop, X);
+  S::forward(X, reinterpret_cast<const cd*>(vs), reinterpret_cast<const cd*>(vp), M, Y, p);
+  const int64_t* cnt = counts + (size_t)c * R;
+  double part = 0.0;
+  for (int r = threadIdx.x; r < R; r += S::NT) part += (double)cnt[r] * log(fabs(p[r] + 1e-12));
+  const double fn = -S::bsum(red, part);
+  if (t < 0) {
+    if (threadIdx.x == 0) fcur[c] = fn;
+    return;
+  }
+  const double f = fcur[c];
+  const bool acc = uniforms[(size_t)c * T_steps + t] <= exp(f - fn);
+  cd* out = reinterpret_cast<cd*>(chain_out) + ((size_t)c * T_steps + t) * S::NE;
+  for (int k = threadIdx.x; k < S::NE; k += S::NT) {
+    const cd v = acc ? prop[k] : cur[k];
+    out[k] = v;
+    if (acc) cur[k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (acc) fcur[c] = fn;
+    accepted[(size_t)c * T_steps + t] = acc ? 1 : 0;
+  }
+}
+
 }  // namespace qt

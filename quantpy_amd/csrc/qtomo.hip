@@ -1591,7 +1591,6 @@ int qt_mhmc_process(qt_handle_t* h, const int64_t* counts, int C, const double* 
   if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
   if (C < 0 || T < 0 || (C > 0 && T > 0 && (!counts || !choi_init || !deltas || !uniforms || !chain || !accepted)))
     return fail(QT_ERR_ARG, "bad mhmc_process arguments");
-  if (h->nq > 2) return fail(QT_ERR_UNSUPPORTED, "the process chain supports n_qubits 1..2 in this release");
   if (C == 0 || T == 0) return 0;
   const int D = h->D, M = h->M;
   const size_t ne = (size_t)D * D;
@@ -1605,6 +1604,34 @@ int qt_mhmc_process(qt_handle_t* h, const int64_t* counts, int C, const double* 
   if (int r = stage_in(h, h->out3, uniforms, (size_t)C * T, flags, &du)) return r;
   if (int r = stage_out(h, h->out0, chain, (size_t)C * T * ne * 2, flags, &dch)) return r;
   if (int r = stage_out(h, h->out1, accepted, (size_t)C * T, flags, &dacc)) return r;
+  if (h->proc.factored) {  // n = 3: three launches per step, the chain's state stays on the device (qt_process64.h)
+    using S = qt::Pgdb64;
+    HIPCHK(h->ws_x.ensure(((size_t)C * S::ws_doubles(M) + C) * sizeof(double)));
+    HIPCHK(h->ws_g.ensure((size_t)C * ne * 2 * sizeof(double)));     // proposals before the projection
+    HIPCHK(h->ws_f.ensure((size_t)C * ne * 2 * sizeof(double)));     // ... and after it
+    HIPCHK(h->hess.ensure((size_t)C * ne * 2 * sizeof(double)));     // the chains' current points
+    HIPCHK(h->proc_ws.ensure((size_t)C * qt::Proc64::kWsComplex * 2 * sizeof(double)));
+    if (int r = allow_big_lds(qt::k_cptp_project64, qt::Proc64::kLdsBytes)) return r;
+    if (int r = allow_big_lds(qt::k_mhmc64_accept, S::kLdsBytes)) return r;
+    double *ws = h->ws_x.as<double>(), *fcur = ws + (size_t)C * S::ws_doubles(M), *x = h->hess.as<double>();
+    const double *vs = (const double*)h->proc.in_states, *vp = (const double*)h->proc.emats;
+    HIPCHK(hipMemcpyAsync(x, dx, (size_t)C * ne * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(qt::k_mhmc64_accept, dim3(C), dim3(S::NT), S::kLdsBytes, h->stream, dc, C, M, T, -1, vs, vp,
+                       (const double*)nullptr, du, x, fcur, ws, dch, dacc);
+    for (int t = 0; t < T; ++t) {
+      hipLaunchKernelGGL(qt::k_mhmc64_propose, dim3(C), dim3(256), 0, h->stream, C, T, t, step, (const double*)x, dd,
+                         h->ws_g.as<double>());
+      hipLaunchKernelGGL(qt::k_cptp_project64, dim3(C), dim3(qt::Proc64::NT), qt::Proc64::kLdsBytes, h->stream,
+                         (const double*)h->ws_g.as<double>(), C, 0, 1000, 1e-12, h->ws_f.as<double>(), (int32_t*)nullptr,
+                         (int32_t*)nullptr, h->proc_ws.as<double>());
+      hipLaunchKernelGGL(qt::k_mhmc64_accept, dim3(C), dim3(S::NT), S::kLdsBytes, h->stream, dc, C, M, T, t, vs, vp,
+                         (const double*)h->ws_f.as<double>(), du, x, fcur, ws, dch, dacc);
+    }
+    HIPCHK(hipGetLastError());
+    if (int r = fetch_out(h, dch, chain, (size_t)C * T * ne * 2, flags)) return r;
+    if (int r = fetch_out(h, dacc, accepted, (size_t)C * T, flags)) return r;
+    return finish(h, flags);
+  }
   const size_t dyn = (size_t)2 * D * M * sizeof(double);
   if (dyn > 32 * 1024) return fail(QT_ERR_UNSUPPORTED, "POVM has too many rows for the process kernel");
   if (D == 4)

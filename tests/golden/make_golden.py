@@ -938,9 +938,38 @@ def gen_pgdb3():
     save("pgdb3", **out)
 
 
+# --------------------------------------------------------------------------------------
+# (f) MHMCProcessInterval at n = 3 (interval.py:763-850 is size-generic): two short chains on the Q0 data
+# --------------------------------------------------------------------------------------
+def gen_mhmc3():
+    import time as _time
+
+    out = {}
+    t0 = _time.time()
+    np.random.seed(31)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 3))
+    tmg.experiment(10000, "proj-set")
+    ch = tmg.point_estimate("lifp")
+    out["M_counts"] = tmg.results
+    out["M_channel"] = ch.choi.matrix
+    print(f"   lifp + cptp: {_time.time() - t0:.0f} s")
+    for key, seed, step, n_points, burn in (("M0", 231, 1e-5, 6, 4), ("M1", 232, 2e-6, 6, 4)):
+        np.random.seed(seed)
+        iv = qp.MHMCProcessInterval(tmg, n_points=n_points, step=step, burn_steps=burn, return_samples=True)
+        dist, cl, rate, mats = iv.setup()
+        out[key + "_seed"] = np.array(seed)
+        out[key + "_args"] = np.array([n_points, burn])
+        out[key + "_step"] = np.array(step)
+        out[key + "_dist"] = dist
+        out[key + "_rate"] = np.array(rate)
+        out[key + "_samples"] = np.stack(mats)
+        print(f"   {key}: step {step} acceptance {rate:.3f} dist {dist[:3]}  ({_time.time() - t0:.0f} s)", flush=True)
+    save("mhmc3", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["operators", "states", "counts", "chol", "mle", "process", "moment", "bootstrap", "large",
-                             "pgdb", "constr", "mhmc", "holder", "leftovers", "process3", "pgdb3"]
+                             "pgdb", "constr", "mhmc", "holder", "leftovers", "process3", "pgdb3", "mhmc3"]
     table = {
         "operators": gen_operators,
         "states": gen_states_and_born,
@@ -954,6 +983,7 @@ if __name__ == "__main__":
         "large": gen_large,
         "pgdb": gen_pgdb,
         "pgdb3": gen_pgdb3,
+        "mhmc3": gen_mhmc3,
         "constr": gen_constr,
         "mhmc": gen_mhmc,
         "holder": gen_holder,

@@ -92,8 +92,9 @@ def test_n3_states_estimator_and_batch(g3):
     # a positive-definite Choi matrix is left alone by the CP step (Cholesky short cut), a clipped one is PSD
     assert np.abs(eng.cptp_project(g3["Q_true_choi"] + 1e-3 * np.eye(64), mode="cp") - (g3["Q_true_choi"] + 1e-3 * np.eye(64))).max() < 1e-15
     assert np.linalg.eigvalsh(eng.cptp_project(g3["Q0_choi_nocptp"], mode="cp")).min() > 0
-    with pytest.raises(RuntimeError):  # the process chain is the one estimator-side piece left at n <= 2
-        eng.mhmc_process(g3["Q0_counts"], np.eye(64) / 64, np.zeros((2, 4096)), np.zeros(2), 0.01)
+    # a chain step whose proposal is the current point itself is accepted for every u <= 1 (exp(0) = 1)
+    chain, accepted = eng.mhmc_process(g3["Q0_counts"], choi[0], np.zeros((2, 4096)), np.array([1.0, 0.3]), 0.01)
+    assert list(accepted) == [1, 1] and np.abs(chain - choi[0]).max() < 1e-9
 
 
 def test_n3_bootstrap_process_interval_runs(g3):
@@ -245,3 +246,27 @@ def test_n3_pgdb_matches_the_reference():
     # the NLL the line search saw (gen_pgdb3 records the reference's f0, f1 and alpha per step): recomputed from the iterates
     alphas = trace[:, 2].real
     assert np.all((alphas > 0) & (alphas <= 1))
+
+
+def test_n3_mhmc_process_interval_matches_the_reference():
+    """MHMCProcessInterval at n = 3 (interval.py:763-850) through the factored chain kernels (k_mhmc64_propose /
+    k_cptp_project64 / k_mhmc64_accept) against two short chains the reference ran on its dense operator
+    (make_golden.py:gen_mhmc3): same proposals and uniforms from the same seeds, the samples, the sorted distances and
+    the acceptance rate."""
+    import quantpy_amd as qp
+
+    g = load_golden("mhmc3")
+    np.random.seed(31)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 3))
+    tmg.experiment(10000, "proj-set")
+    assert np.array_equal(tmg.results, g["M_counts"])
+    ch = tmg.point_estimate("lifp")
+    assert np.abs(ch.choi.matrix - g["M_channel"]).max() < 1e-9
+    for key in ("M0", "M1"):
+        n_points, burn = (int(v) for v in g[key + "_args"])
+        np.random.seed(int(g[key + "_seed"]))
+        iv = qp.MHMCProcessInterval(tmg, n_points=n_points, step=float(g[key + "_step"]), burn_steps=burn, return_samples=True)
+        dist, cl, rate, mats = iv.setup()
+        assert abs(rate - float(g[key + "_rate"])) < 1e-12, (key, rate, float(g[key + "_rate"]))
+        assert np.abs(np.stack(mats) - g[key + "_samples"]).max() < 1e-8, key
+        assert np.abs(dist - g[key + "_dist"]).max() < 1e-8, key

@@ -37,6 +37,22 @@ class Mode(Enum):
     CHANNEL = auto()
 
 
+def _proposal_increments(dim):
+    """size -> (size, dim) proposal increments of a chain, drawn as the reference draws them: scipy's frozen
+    `multivariate_normal(mean=zeros(dim))` (mhmc.py / interval.py:735-738, :822-825) on np.random's global stream.
+    That call ends in `RandomState.multivariate_normal`, which draws standard_normal((size, dim)) and multiplies by
+    sqrt(s) v of svd(cov); for the identity covariance LAPACK returns s = 1, v = I exactly, so the product is the draws
+    themselves.  Up to dim 256 the reference's own call is made; above (three-qubit processes: dim 4096, where the
+    eigen-decomposition in the constructor and the SVD per call cost ~20 s each) the draws are taken directly -- the
+    n = 3 chains of tests/golden/mhmc3.npz, made by the reference through the full call, pin the equivalence."""
+    if dim <= 256:
+        from scipy.stats import multivariate_normal
+
+        frozen = multivariate_normal(mean=np.zeros(dim))
+        return lambda size: frozen.rvs(size=size).reshape(size, dim)
+    return lambda size: np.random.standard_normal((size, dim))
+
+
 def _pop_hidden_keys(kwargs):
     return {k: v for k, v in kwargs.items() if k not in ("self", "tmg") and not k.startswith("__")}
 
@@ -197,7 +213,6 @@ class MHMCStateInterval(ConfidenceInterval):
         super().__init__(tmg, **_pop_hidden_keys(locals()))
 
     def setup(self):
-        from scipy.stats import multivariate_normal
 
         if self.mode == Mode.CHANNEL:
             raise NotImplementedError("This interval works only for state tomography")
@@ -213,12 +228,12 @@ class MHMCStateInterval(ConfidenceInterval):
             if status == 1:  # the reference fails inside scipy.linalg.cholesky here
                 raise np.linalg.LinAlgError("the state the chain starts from is not positive definite")
             self._x_t, self._burned = x0, False
-        jump = multivariate_normal(mean=np.zeros(dim))
+        jump = _proposal_increments(dim)
         parts = []
         if not self._burned:
-            parts.append((jump.rvs(size=self.burn_steps).reshape(self.burn_steps, dim), np.random.rand(self.burn_steps)))
+            parts.append((jump(self.burn_steps), np.random.rand(self.burn_steps)))
         total = self.n_points * self.thinning
-        parts.append((jump.rvs(size=total).reshape(total, dim), np.random.rand(total)))
+        parts.append((jump(total), np.random.rand(total)))
         deltas = np.concatenate([p[0] for p in parts])
         uniforms = np.concatenate([p[1] for p in parts])
         chain, accepted = eng.mhmc_state(tmg.results, self._x_t, deltas, uniforms, self.step)
@@ -341,7 +356,6 @@ class MHMCProcessInterval(ConfidenceInterval):
         super().__init__(tmg, **_pop_hidden_keys(locals()))
 
     def setup(self):
-        from scipy.stats import multivariate_normal
 
         if self.mode == Mode.STATE:
             raise NotImplementedError("This interval works only for process tomography")
@@ -356,12 +370,12 @@ class MHMCProcessInterval(ConfidenceInterval):
         centre = np.asarray(self.channel.choi.matrix, dtype=np.complex128)
         if not (self.warm_start and hasattr(self, "_x_t")):
             self._x_t, self._burned = centre.copy(), False
-        jump = multivariate_normal(mean=np.zeros(dim))
+        jump = _proposal_increments(dim)
         parts = []
         if not self._burned:
-            parts.append((jump.rvs(size=self.burn_steps).reshape(self.burn_steps, dim), np.random.rand(self.burn_steps)))
+            parts.append((jump(self.burn_steps), np.random.rand(self.burn_steps)))
         total = self.n_points * self.thinning
-        parts.append((jump.rvs(size=total).reshape(total, dim), np.random.rand(total)))
+        parts.append((jump(total), np.random.rand(total)))
         deltas = np.concatenate([p[0] for p in parts])
         uniforms = np.concatenate([p[1] for p in parts])
         chain, accepted = eng.mhmc_process(tmg.results, self._x_t, deltas, uniforms, self.step)

@@ -445,3 +445,23 @@ def test_philox4x32_10_known_answers():
         c, k, out = np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
         lib.qt_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
         assert out.tolist() == want, [hex(v) for v in out]
+
+
+def test_chain_proposal_increments_are_the_references_draws():
+    """interval._proposal_increments: above dim 256 the draws skip scipy's frozen multivariate_normal (identity
+    covariance: an eigen-decomposition and an SVD that return the identity) -- same numbers, same stream position."""
+    from scipy.stats import multivariate_normal
+
+    from quantpy_amd.tomography.interval import _proposal_increments
+
+    for dim in (16, 320):
+        np.random.seed(dim)
+        want = multivariate_normal(mean=np.zeros(dim)).rvs(size=7).reshape(7, dim)
+        after_want = np.random.rand()
+        np.random.seed(dim)
+        got = _proposal_increments(dim)(7)
+        assert np.array_equal(got, want) and np.random.rand() == after_want
+        np.random.seed(dim + 1)
+        one = _proposal_increments(dim)(1)
+        np.random.seed(dim + 1)
+        assert np.array_equal(one, multivariate_normal(mean=np.zeros(dim)).rvs(size=1).reshape(1, dim))

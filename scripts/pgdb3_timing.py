@@ -26,3 +26,15 @@ t0 = time.perf_counter()
 for _ in range(5):
     eng.pgdb_pieces(tmg.results, np.eye(64) / 64)
 print(f"qt_pgdb_pieces (one process: model, gradient, CPTP projection of the trial point): {1e3 * (time.perf_counter() - t0) / 5:.2f} ms")
+# the Metropolis-Hastings process chain (MHMCProcessInterval) at n = 3: 3 launches per step, no host round trip
+ch = tmg.point_estimate("lifp")
+for step in (1e-5, 2e-6):
+    for T in (20, 200):
+        np.random.seed(1)
+        deltas, uniforms = np.random.standard_normal((T, 4096)), np.random.rand(T)
+        eng.mhmc_process(tmg.results, ch.choi.matrix, deltas, uniforms, step)
+        t0 = time.perf_counter()
+        chain, acc = eng.mhmc_process(tmg.results, ch.choi.matrix, deltas, uniforms, step)
+        dt = time.perf_counter() - t0
+        print(f"chain: step {step:g}, T={T:4d}: {1e3 * dt:8.2f} ms = {1e3 * dt / T:6.3f} ms per step, acceptance {acc.mean():.2f} "
+              f"(incl. D2H of the {chain.nbytes / 1e6:.1f} MB chain)", flush=True)

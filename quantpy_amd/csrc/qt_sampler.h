@@ -247,12 +247,15 @@ QT_SAMPLER_HD inline void legacy_multinomial(G& g, int64_t n, const double* pval
 // Opt-in device sampler: row r (= resample r / period, setting r % period) is drawn by one thread from its own Philox
 // stream (seed, first_row + r), so the counts of a row depend on nothing but (seed, global row index, n, p): any
 // split of the rows over launches or ranks gives the same table.  The same conditional-binomial chain as above;
-// the rows of one setting sit `period` threads apart, neighbouring lanes work on different settings of one
-// resample (same n, similar p: mostly the same branch).  out is [rows][K] int64, what the estimators read.
-__global__ void __launch_bounds__(256) k_multinomial_rows(uint64_t seed, uint64_t first_row, long long rows, int period,
+// out is [rows][K] int64, what the estimators read.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_multinomial_rows(uint64_t seed, uint64_t first_row, long long rows, int period,
                                                           const int64_t* __restrict__ n, const double* __restrict__ pvals,
                                                           int K, int64_t* __restrict__ out) {
-  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // thread -> row: a wavefront takes ONE setting of 64 consecutive resamples (same n, same p: one branch structure
+  // through the set-up and the choice inversion / BTPE), `period` wavefronts cover a block of 64 x period rows
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long span = 64LL * period;
+  const long long r = (gid / span * 64 + (gid % span) % 64) * period + (gid % span) / 64;
   if (r >= rows) return;
   const int s = (int)((first_row + (uint64_t)r) % (uint64_t)period);
   Philox g(seed, first_row + (uint64_t)r, 0u);

@@ -1249,7 +1249,8 @@ int qt_device_multinomial(qt_handle_t* h, uint64_t seed, uint64_t first_row, lon
   if (int r = stage_in(h, h->in0, n, (size_t)period, flags, &dn)) return r;
   if (int r = stage_in(h, h->in1, pvals, (size_t)period * K, flags, &dp)) return r;
   if (int r = stage_out(h, h->out0, out, (size_t)rows * K, flags, &dout)) return r;
-  hipLaunchKernelGGL(qt_sampler::k_multinomial_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, seed,
+  const long long span = 64LL * period, threads = (rows + span - 1) / span * span;  // whole 64 x period blocks of rows
+  hipLaunchKernelGGL(qt_sampler::k_multinomial_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, seed,
                      first_row, rows, period, dn, dp, K, dout);
   if (int r = fetch_out(h, (const int64_t*)dout, out, (size_t)rows * K, flags)) return r;
   return finish(h, flags);

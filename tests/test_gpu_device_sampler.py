@@ -17,7 +17,8 @@ def eng():
     return qp.get_engine(1)
 
 
-@pytest.mark.parametrize("n,p", [(40, 0.05), (25, 0.5), (1000, 0.3), (1000, 0.93), (10**6, 0.5), (10**6, 2e-5), (7, 0.999)])
+@pytest.mark.parametrize("n,p", [(40, 0.05), (25, 0.5), (1000, 0.3), (1000, 0.93), (10**6, 0.5), (10**6, 2e-5), (7, 0.999),
+                                 (400, 0.1), (2000, 0.02), (150, 0.4), (61, 0.5), (100000, 0.125)])
 def test_binomial_marginal_chi_square(eng, n, p):
     """K = 2 rows are single binomials: inversion (n p <= 30), BTPE (above), and the p > 0.5 reflection."""
     from scipy import stats

@@ -549,5 +549,15 @@ def get_engine(n_qubits, device=None):
     return eng
 
 
+def any_engine(device=None):
+    """An engine of this process's GPU for work that does not depend on the qubit number (the device sampler, sorting):
+    one that exists already, else the one-qubit engine."""
+    dev = default_device() if device is None else int(device)
+    for (_, d), eng in _ENGINES.items():
+        if d == dev:
+            return eng
+    return get_engine(1, dev)
+
+
 def status_text(code):
     return _STATUS_TEXT.get(int(code), "ok")

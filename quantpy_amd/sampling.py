@@ -92,6 +92,14 @@ def legacy_multinomial(n, pvals, repeats=1):
 SAMPLERS = ("numpy", "device")
 
 
+def resolve_seed(seed):
+    """64-bit Philox key: the caller's, or two words of np.random's global stream (np.random.seed keeps a run reproducible)."""
+    if seed is None:
+        lo, hi = (int(w) for w in np.random.randint(0, 2**32, size=2, dtype=np.uint64))
+        seed = lo | (hi << 32)
+    return int(seed) & (2**64 - 1)
+
+
 def device_multinomial(n, pvals, repeats=1, seed=None, engine=None):
     """The table `legacy_multinomial` returns, in distribution: int64 (repeats, S, K) with row (r, s) ~
     multinomial(n[s], pvals[s]), drawn on the GPU from the Philox stream (seed, r * S + s).  seed=None takes 64 bits
@@ -104,13 +112,11 @@ def device_multinomial(n, pvals, repeats=1, seed=None, engine=None):
     n = np.ascontiguousarray(np.asarray(n).astype(np.int64))
     if n.shape != (n_set,):
         raise ValueError("one `n` per row of pvals")
-    if seed is None:
-        lo, hi = (int(w) for w in np.random.randint(0, 2**32, size=2, dtype=np.uint64))
-        seed = lo | (hi << 32)
+    seed = resolve_seed(seed)
     if engine is None:
-        from .engine import get_engine
+        from .engine import any_engine
 
-        engine = get_engine(1)
+        engine = any_engine()
     from .engine import EngineError
 
     try:

@@ -176,6 +176,11 @@ class BootstrapStateInterval(ConfidenceInterval):
                 self.state = tmg.point_estimate(method=self.method, physical=self.physical, init=self.init,
                                                 tol=self.tol, max_iter=self.max_iter)
         boot = tmg.__class__(self.state, tmg.dst)
+        if (self.sampler == "device" and self.n_points and qdist.world()[1] == 1 and tmg.dst is hs_dst
+                and self.method in ("lin", "mle")):
+            self.boot_dist = self._setup_on_device(boot)
+            self._finish(self.boot_dist)
+            return
         # every resample's counts, one global RNG stream in the reference's order (resample after resample, setting
         # after setting): ONE call of the C restatement of NumPy's sampler instead of n_points x S Python calls
         # (sampler='device', opt-in: the same distribution drawn on the GPU, off the reference's stream)
@@ -198,6 +203,58 @@ class BootstrapStateInterval(ConfidenceInterval):
 
         self.boot_dist = qdist.sharded_map(counts, reconstruct)
         self._finish(self.boot_dist)
+
+
+    def _setup_on_device(self, boot):
+        """sampler='device' on one GPU with the Hilbert-Schmidt distance: draws (qt_device_multinomial), reconstructions
+        and distances are enqueued back to back and stay in HBM; the distances come back.  `boot_counts` is fetched only
+        if somebody reads it."""
+        import torch
+
+        from ..sampling import resolve_seed
+        from .state import born_probabilities
+        from .. import _capi
+
+        tmg = self.tmg
+        povm_matrix, shots = boot._experiment_arguments(tmg.n_measurements, tmg.povm_matrix)
+        pvals = born_probabilities(povm_matrix, self.state.bloch)
+        if not (np.all(pvals >= 0) and np.all(pvals[:, :-1].sum(1) <= 1.0 + 1e-12)):
+            raise ValueError("sum(pvals[:-1]) > 1.0")
+        boot.povm_matrix, boot.n_measurements = povm_matrix, np.asarray(shots)
+        eng = boot._engine()
+        n_set, n_out = pvals.shape
+        b, d = self.n_points, 2 ** self.state.n_qubits
+        dev = torch.device("cuda", eng.device)
+        counts = torch.empty((b, n_set, n_out), dtype=torch.int64, device=dev)
+        eng.device_multinomial(np.asarray(shots).astype(np.int64), pvals, b * n_set, resolve_seed(self.seed), out=counts)
+        rho = torch.empty((b, d, d), dtype=torch.complex128, device=dev)
+        status = torch.zeros(b, dtype=torch.int32, device=dev)
+        if self.method == "lin":
+            eng.lin_dev(counts, rho, physical=self.physical, status=status)
+        else:
+            eng.mle_dev(counts, rho, init=self.init, max_iter=self.max_iter, tol=self.tol, status=status)
+        dist = torch.empty(b, dtype=torch.float64, device=dev)
+        centre = torch.from_numpy(np.ascontiguousarray(self.state.matrix, dtype=np.complex128)).to(dev)
+        eng.hs_dist_dev(rho, centre, dist)
+        eng.sync()
+        st = status.cpu().numpy()
+        if np.any(st == 1):
+            raise np.linalg.LinAlgError("starting point of the MLE is not positive definite")
+        if np.any(st == _capi.TRIAL_SHOTS):
+            raise ValueError("per-setting totals of a trial do not match the registered shots")
+        self._boot_counts_device = counts
+        boot.results = counts[-1].cpu().numpy()  # the tomograph is left as the last experiment() would leave it
+        return dist.cpu().numpy()
+
+    @property
+    def boot_counts(self):
+        if getattr(self, "_boot_counts_host", None) is None and getattr(self, "_boot_counts_device", None) is not None:
+            self._boot_counts_host = self._boot_counts_device.cpu().numpy()
+        return getattr(self, "_boot_counts_host", None)
+
+    @boot_counts.setter
+    def boot_counts(self, value):
+        self._boot_counts_host, self._boot_counts_device = value, None
 
 
 class MHMCStateInterval(ConfidenceInterval):

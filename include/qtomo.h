@@ -58,8 +58,9 @@ int qt_version(void);
 const char* qt_last_error(void);
 /* number of HIP devices visible, or a negative qt_status */
 int qt_device_count(void);
-/* n_qubits in 1..5.  Estimators: any POVM for n <= 3; n = 4, 5 need a product POVM
- * (qt_set_povm_product).  Process tomography: n <= 2. */
+/* n_qubits in 1..5.  State estimators: any POVM at every n (n = 4, 5: a product POVM registered with
+ * qt_set_povm_product contracts qubit by qubit; a plain tensor takes the streaming dense path).  Process
+ * tomography: n <= 3 (n = 3 through the Kronecker factors of the design matrix, see qt_process_setup). */
 qt_handle_t* qt_create(int device, int n_qubits);
 void qt_destroy(qt_handle_t* h);
 int qt_sync(qt_handle_t* h);
@@ -150,6 +151,12 @@ void qt_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out);
 int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, double* rho, double* bloch_out,
                  int32_t* status, int flags);
 
+/* ---- a6/a7 + a16 in one pass: the body of the bootstrap loop, quantpy/tomography/interval.py:600-609 -------
+ * qt_lin_batch plus dist[b] = hs_dst(estimate_b, centre) (geometry.py:5-20, as qt_hs_dist_batch computes it).
+ * centre[d][d][2]; rho is NULLABLE here: a bootstrap needs one double per resample, not the matrices. */
+int qt_lin_dist_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, const double* centre, double* rho,
+                      double* dist, int32_t* status, int flags);
+
 /* ---- a8: quantpy/routines.py:84-101 Cholesky parametrisation ------------------------------- */
 /* x[B][D] = [diag L | Re L_(i>j) | Im L_(i>j)] (strict lower in np.tril_indices order) of
  * rho[B][d][d][2] = L L^dagger ; and back (LLh = L L^dagger, not normalised) */
@@ -169,6 +176,12 @@ int qt_nll_batch(qt_handle_t* h, const double* x, const int64_t* counts, int B, 
 int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol, double* rho,
                  int32_t* nit, int32_t* nfev, double* fun, int32_t* status, int flags);
 
+/* ---- a8-a10 + a16 in one pass (interval.py:600-609 with method='mle'): qt_mle_batch plus the Hilbert-Schmidt
+ * distance of every estimate to centre[d][d][2]; rho NULLABLE (8 bytes written per resample instead of 16 d^2). */
+int qt_mle_dist_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol,
+                      const double* centre, double* rho, double* dist, int32_t* nit, int32_t* nfev, double* fun,
+                      int32_t* status, int flags);
+
 /* ---- a16: quantpy/geometry.py:5-20 hs_dst --------------------------------------------------- */
 /* dist[b] = sqrt(|Tr((rho_b - centre)^2)|) / sqrt(2), set to 0 below 1e-15 */
 int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, int B, double* dist, int flags);
@@ -182,6 +195,30 @@ int qt_sort_f64(qt_handle_t* h, double* x, long long n, int flags);
  * x_i = i / (n - 1); out[n_levels].  A level outside [0, 1] gives NaN (interp1d raises there). */
 int qt_sorted_quantiles(qt_handle_t* h, const double* sorted, long long n, const double* conf_levels, int n_levels,
                         double* out, int flags);
+
+/* ---- a16 when the distances are spread over N ranks (one process per GPU): interval.py:610-612 without gathering
+ * the sample.  Every rank sorts ITS shard (qt_sort_f64); interp1d at a confidence level q needs the order statistics
+ * k0 = floor-cell(q) and k0 + 1 of the union only.  Four small steps with two all-gathers of a few KB in between
+ * (quantpy_amd/distributed.py does those with torch.distributed; the C ABI stays free of collectives):
+ *   qt_select_splitters : splitters[j] = sorted[j * stride], j < P (padded behind everything)        -> all-gather [N][P]
+ *   qt_select_bracket   : from all ranks' splitters and shard sizes: per level the tightest splitter pair
+ *                         (lo, hi] that provably holds both order statistics (as radix-sort keys; 0 / ~0 = none)
+ *   qt_select_window    : window[l] = { #values <= lo, w = #values in (lo, hi], the first min(w, W) of them } -> all-gather
+ *   qt_select_finish    : out[l] = interp1d(linspace(0, 1, n_total), sorted union)(conf_levels[l]); *overflow != 0 when a
+ *                         window was clipped (w > W, heavy ties) or the union exceeds the kernel's capacity: the caller
+ *                         then gathers the sorted shards and merges them (qt_merge_sorted) instead.
+ * W >= (2 N + 3) * stride covers every sample without massive ties.  Same results as np.sort + interp1d, bit for bit. */
+int qt_select_splitters(qt_handle_t* h, const double* sorted, long long n, long long stride, int P, double* splitters,
+                        int flags);
+int qt_select_bracket(qt_handle_t* h, const double* splitters, int N, int P, const int64_t* sizes, long long stride,
+                      long long n_total, const double* conf_levels, int L, uint64_t* lo_key, uint64_t* hi_key, int flags);
+int qt_select_window(qt_handle_t* h, const double* sorted, long long n, const uint64_t* lo_key, const uint64_t* hi_key, int L,
+                     int W, double* window, int flags);
+int qt_select_finish(qt_handle_t* h, const double* windows, int N, int L, int W, long long n_total, const double* conf_levels,
+                     double* out, int32_t* overflow, int flags);
+/* R sorted runs stored back to back in runs (run_lengths[R]: always a HOST array) -> out: their merge in np.sort's
+ * order (NaN last), by ceil(log2 R) merge-path passes.  out must not alias runs. */
+int qt_merge_sorted(qt_handle_t* h, const double* runs, const int64_t* run_lengths, int R, double* out, int flags);
 
 /* Metropolis-Hastings chains on the Cholesky parameters (mhmc.py:80-119 with `normalized_update`, used by
  * MHMCStateInterval, interval.py:735-750): C independent chains (the reference runs one), each on its

@@ -46,15 +46,23 @@ SIGNATURES = {
     "qt_bloch_from_mat": (_c_int, [_vp, _vp, _c_int, _vp, _c_int]),
     "qt_mat_from_bloch": (_c_int, [_vp, _vp, _c_int, _vp, _c_int]),
     "qt_lin_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _c_int]),
+    "qt_lin_dist_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int]),
     "qt_chol_param": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _c_int]),
     "qt_chol_unparam": (_c_int, [_vp, _vp, _c_int, _vp, _c_int]),
     "qt_nll_batch": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _vp, _c_int]),
     "qt_mle_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, _vp, _vp, _vp, _vp, _c_int]),
+    "qt_mle_dist_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int]),
     "qt_mhmc_state": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _c_int]),
     "qt_hs_dist_batch": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int]),
     "qt_hs_dist_dim": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, _vp, _c_int]),
     "qt_sort_f64": (_c_int, [_vp, _vp, ctypes.c_longlong, _c_int]),
     "qt_sorted_quantiles": (_c_int, [_vp, _vp, ctypes.c_longlong, _vp, _c_int, _vp, _c_int]),
+    "qt_select_splitters": (_c_int, [_vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _c_int, _vp, _c_int]),
+    "qt_select_bracket": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _c_int, _vp, _vp,
+                                   _c_int]),
+    "qt_select_window": (_c_int, [_vp, _vp, ctypes.c_longlong, _vp, _vp, _c_int, _c_int, _vp, _c_int]),
+    "qt_select_finish": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp, _vp, _vp, _c_int]),
+    "qt_merge_sorted": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int]),
     "qt_legacy_multinomial": (_c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp]),
     "qt_device_multinomial": (_c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp,
                                        _c_int]),

@@ -112,6 +112,30 @@ struct Large {
     return s;
   }
 
+  // Result of the workgroup's trial, element (i, j) = r per thread: store it and / or its Hilbert-Schmidt distance to
+  // o.centre (geometry.py:16-20; Tr(Delta Delta) = sum_ij Delta_ij Delta_ji, the transposed element through the L image,
+  // which no estimator reads after its last build_llh).  Called by every thread of the workgroup.
+  __device__ static void emit(const Ctx& c, const EstOut& o, int b, cd r) {
+    if (o.dist) {  // uniform over the launch
+      const double2 cc = *reinterpret_cast<const double2*>(o.centre + 2 * c.t);
+      const cd dl{r.re - cc.x, r.im - cc.y};
+      cd* L = c.L();
+      __syncthreads();
+      L[c.e] = dl;
+      __syncthreads();
+      const cd dt = L[c.j * LD + c.i];
+      const double sr = bsum(c, dl.re * dt.re - dl.im * dt.im);
+      const double si = bsum(c, dl.re * dt.im + dl.im * dt.re);
+      const double v = sqrt(hypot(sr, si)) / sqrt(2.0);
+      if (c.t == 0) o.dist[b] = v < 1e-15 ? 0.0 : v;
+    }
+    if (o.rho) {
+      double* out = o.rho + ((size_t)b * D + c.t) * 2;
+      out[0] = r.re;
+      out[1] = r.im;
+    }
+  }
+
   __device__ static void make_ctx(Ctx& c, double* smem, const PovmView& pv, const int64_t* counts) {
     c.t = threadIdx.x;
     c.i = c.t / d;
@@ -682,7 +706,7 @@ struct Large {
 
 template <int NQ>
 __global__ void __launch_bounds__(Large<NQ>::NT) k_lin_large(PovmView pv, const int64_t* __restrict__ counts, int B,
-                                                             int physical, double* __restrict__ rho,
+                                                             int physical, EstOut rho,
                                                              double* __restrict__ bloch_out, int32_t* __restrict__ status) {
   using S = Large<NQ>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -693,9 +717,7 @@ __global__ void __launch_bounds__(Large<NQ>::NT) k_lin_large(PovmView pv, const 
   double bl;
   cd r = S::lin_invert(c, bl);
   if (physical) r = S::make_feasible(c, r, nullptr, nullptr);
-  double* out = rho + ((size_t)b * S::D + c.t) * 2;
-  out[0] = r.re;
-  out[1] = r.im;
+  S::emit(c, rho, b, r);
   if (bloch_out) bloch_out[(size_t)b * S::D + c.t] = bl;
   if (status && c.t == 0) status[b] = !c.shots_ok ? 5 : (r.re == r.re) ? 0 : 4;
 }
@@ -795,7 +817,7 @@ template <int NQ>
 __global__ void __launch_bounds__(Large<NQ>::NT) __attribute__((amdgpu_waves_per_eu(4)))
 k_mle_large_start(PovmView pv, const int64_t* __restrict__ counts, int B,
                                                                    int init, int max_iter, double gtol,
-                                                                   double* __restrict__ rho, int32_t* __restrict__ nit_out,
+                                                                   EstOut rho, int32_t* __restrict__ nit_out,
                                                                    int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,
                                                                    int32_t* __restrict__ status_out, double* __restrict__ ws_x,
                                                                    double* __restrict__ ws_g, double* __restrict__ ws_f,
@@ -837,9 +859,7 @@ k_mle_large_start(PovmView pv, const int64_t* __restrict__ counts, int B,
   // what the trial returns if BFGS does not move: L L^dagger / Tr at x_k (state.py:214-215)
   double tr;
   const cd m = S::build_llh(c, xk, tr);
-  double* out = rho + ((size_t)b * D + c.t) * 2;
-  out[0] = m.re / tr;
-  out[1] = m.im / tr;
+  S::emit(c, rho, b, cd{m.re / tr, m.im / tr});
   if (iterate) {
     ws_x[(size_t)b * D + c.t] = xk;
     ws_g[(size_t)b * D + c.t] = gk;
@@ -858,7 +878,7 @@ k_mle_large_start(PovmView pv, const int64_t* __restrict__ counts, int B,
 template <int NQ>
 __global__ void __launch_bounds__(Large<NQ>::NT) __attribute__((amdgpu_waves_per_eu(4)))
 k_mle_large_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B,
-                                                                  int max_iter, double gtol, double* __restrict__ rho,
+                                                                  int max_iter, double gtol, EstOut rho,
                                                                   int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
                                                                   double* __restrict__ fun_out, int32_t* __restrict__ status_out,
                                                                   const double* __restrict__ ws_x, const double* __restrict__ ws_g,
@@ -976,9 +996,7 @@ k_mle_large_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B,
   }
   double tr;
   const cd m = S::build_llh(c, xk, tr);
-  double* out = rho + ((size_t)b * D + c.t) * 2;
-  out[0] = m.re / tr;
-  out[1] = m.im / tr;
+  S::emit(c, rho, b, cd{m.re / tr, m.im / tr});
   if (c.t == 0) {
     if (nit_out) nit_out[b] = kiter;
     if (nfev_out) nfev_out[b] = nfev;

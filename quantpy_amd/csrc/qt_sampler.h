@@ -24,7 +24,11 @@ namespace qt_sampler {
 
 #pragma clang fp contract(off)
 
+#if defined(__HIPCC__)
 #define QT_SAMPLER_HD __host__ __device__
+#else  // plain host compiler: tests/host/sampler_host.cpp under g++ -fsanitize=address,undefined
+#define QT_SAMPLER_HD
+#endif
 
 struct Mt19937 {
   uint32_t* key;  // [624], updated in place
@@ -244,6 +248,7 @@ QT_SAMPLER_HD inline void legacy_multinomial(G& g, int64_t n, const double* pval
   if (dn > 0) out[K - 1] = dn;
 }
 
+#if defined(__HIPCC__)
 // Opt-in device sampler: row r (= resample r / period, setting r % period) is drawn by one thread from its own Philox
 // stream (seed, first_row + r), so the counts of a row depend on nothing but (seed, global row index, n, p): any
 // split of the rows over launches or ranks gives the same table.  The same conditional-binomial chain as above;
@@ -277,5 +282,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   for (; j < K - 1; ++j) o[j] = 0;
   o[K - 1] = dn > 0 ? dn : 0;
 }
+
+#endif  // __HIPCC__
 
 }  // namespace qt_sampler

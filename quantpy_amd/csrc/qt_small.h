@@ -301,6 +301,15 @@ __device__ __forceinline__ bool shots_match(double t_s, double total, double n_s
   return fabs(a - b) <= 2e-15 * fabs(b);
 }
 
+// Where an estimator leaves a trial's result: the density matrix and / or -- the body of the bootstrap loop,
+// interval.py:600-609, `dist[i] = dst(point_estimate(...), state)` -- its Hilbert-Schmidt distance (geometry.py:16-20) to
+// `centre`.  With `dist` set and `rho` null a resample costs 8 bytes of HBM writes instead of 16 d^2 and no second pass.
+struct EstOut {
+  double* rho;           // [B][d][d][2], or nullptr when only the distance is wanted
+  const double* centre;  // [d][d][2], read when dist != nullptr
+  double* dist;          // [B], or nullptr
+};
+
 template <int NQ, bool ALDS>
 struct Small {
   static constexpr int d = 1 << NQ;
@@ -1258,6 +1267,33 @@ struct Small {
     wave_sync();
     QT_STAMP(18);
   }
+
+  // sqrt(|Tr((R - C)^2)|) / sqrt(2) for the matrix R held one element (i, j) per lane (geometry.py:16-20):
+  // Tr(Delta Delta) = sum_ij Delta_ij Delta_ji, the transposed element fetched from lane (j, i) of the group.
+  // Executed by every lane of the wavefront (DPP reductions); every lane of a group returns the same bits.
+  __device__ __forceinline__ static double hs_to_centre(const Ctx& c, cd r, const double* __restrict__ centre) {
+    const double2 cc = *reinterpret_cast<const double2*>(centre + 2 * c.l);
+    const cd dl{r.re - cc.x, r.im - cc.y};
+    const int src = (int)(threadIdx.x & 63) - c.l + c.j * d + c.i;
+    const cd dt{__shfl(dl.re, src, 64), __shfl(dl.im, src, 64)};
+    const double sr = gsum<G>(dl.re * dt.re - dl.im * dt.im);
+    const double si = gsum<G>(dl.re * dt.im + dl.im * dt.re);
+    const double v = sqrt(hypot(sr, si)) / sqrt(2.0);
+    return v < 1e-15 ? 0.0 : v;
+  }
+  // Result of trial b: element (i, j) = r.  `store` = this lane's group owns a live trial; the distance is computed by
+  // all lanes (o.dist is uniform over the launch), only the stores are masked.
+  __device__ __forceinline__ static void emit(const Ctx& c, const EstOut& o, int b, bool store, cd r) {
+    if (o.dist) {
+      const double v = hs_to_centre(c, r, o.centre);
+      if (store && c.l == 0) o.dist[b] = v;
+    }
+    if (store && o.rho) {
+      double* out = o.rho + ((size_t)b * D + c.l) * 2;
+      out[0] = r.re;
+      out[1] = r.im;
+    }
+  }
 };
 
 // =========================================================================================
@@ -1267,7 +1303,7 @@ struct Small {
 // a6 + a7
 template <int NQ, bool ALDS>
 __global__ void __launch_bounds__(256) k_lin_batch(PovmView pv, const int64_t* __restrict__ counts, int B, int physical,
-                                                   double* __restrict__ rho, double* __restrict__ bloch_out,
+                                                   EstOut rho, double* __restrict__ bloch_out,
                                                    int32_t* __restrict__ status) {
   using S = Small<NQ, ALDS>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1287,10 +1323,8 @@ __global__ void __launch_bounds__(256) k_lin_batch(PovmView pv, const int64_t* _
   QT_STAMP(2);
   if (physical) r = S::make_feasible(c, r, nullptr, nullptr);
   QT_STAMP(9);
+  S::emit(c, rho, b, live, r);
   if (live) {
-    double* out = rho + ((size_t)b * S::D + c.l) * 2;
-    out[0] = r.re;
-    out[1] = r.im;
     if (bloch_out) bloch_out[(size_t)b * S::D + c.l] = bl;
     if (status && c.l == 0) status[b] = !shots_ok ? 5 : (r.re == r.re) ? 0 : 4;
   }
@@ -1365,7 +1399,7 @@ __global__ void __launch_bounds__(256) k_nll_batch(PovmView pv, const double* __
 // keeps its register footprint small.
 template <int NQ, bool ALDS>
 __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* __restrict__ counts, int B, int init,
-                                                   int max_iter, double gtol, double* __restrict__ rho,
+                                                   int max_iter, double gtol, EstOut rho,
                                                    int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
                                                    double* __restrict__ fun_out, int32_t* __restrict__ status_out,
                                                    double* __restrict__ ws_x, double* __restrict__ ws_g,
@@ -1409,10 +1443,8 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
     if (0 >= max_iter) status = 3;
     else if (gnorm != gnorm || fk != fk || xn != xn) status = 4;
   }
+  S::emit(c, rho, b, live, rho_l);
   if (live) {
-    double* out = rho + ((size_t)b * D + c.l) * 2;
-    out[0] = rho_l.re;
-    out[1] = rho_l.im;
     if (iterate) {  // the hand-off is written only for trials that go on to k_mle_bfgs
       ws_x[(size_t)b * D + c.l] = xk;
       ws_g[(size_t)b * D + c.l] = gk;
@@ -1434,7 +1466,7 @@ __global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* _
 // iterate; the others idle through the evaluations on finite dummy values.
 template <int NQ, bool ALDS>
 __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx& c, bool mine, double xk, double gk,
-                                             double fk, int b, int max_iter, double gtol, double* __restrict__ rho,
+                                             double fk, int b, int max_iter, double gtol, EstOut rho,
                                              int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
                                              double* __restrict__ fun_out, int32_t* __restrict__ status_out) {
   using S = Small<NQ, ALDS>;
@@ -1552,10 +1584,8 @@ __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx
   // ---- result: L L^dagger / Tr  (state.py:214-215)
   double tr;
   const cd m = S::build_llh(c, xk, tr);
+  S::emit(c, rho, b, mine, cd{m.re / tr, m.im / tr});
   if (mine) {
-    double* out = rho + ((size_t)b * D + c.l) * 2;
-    out[0] = m.re / tr;
-    out[1] = m.im / tr;
     if (c.l == 0) {
       if (nit_out) nit_out[b] = kiter;
       if (nfev_out) nfev_out[b] = nfev;
@@ -1578,7 +1608,7 @@ __device__ __forceinline__ void bfgs_iterate(const typename Small<NQ, ALDS>::Ctx
 // ones go to the global workspace -- a lone wave would otherwise wait out an L2 round trip per block of pairs.
 template <int NQ, bool ALDS, int LP = 0>
 __device__ __forceinline__ void bfgs_iterate_2l(const typename Small<NQ, ALDS>::Ctx& c, bool mine, double xk, double gk,
-                                                double fk, int b, int max_iter, double gtol, double* __restrict__ rho,
+                                                double fk, int b, int max_iter, double gtol, EstOut rho,
                                                 int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
                                                 double* __restrict__ fun_out, int32_t* __restrict__ status_out,
                                                 double* __restrict__ pairs) {
@@ -1694,10 +1724,8 @@ __device__ __forceinline__ void bfgs_iterate_2l(const typename Small<NQ, ALDS>::
   }
   double tr;
   const cd m = S::build_llh(c, xk, tr);
+  S::emit(c, rho, b, mine, cd{m.re / tr, m.im / tr});
   if (mine) {
-    double* out = rho + ((size_t)b * D + c.l) * 2;
-    out[0] = m.re / tr;
-    out[1] = m.im / tr;
     if (c.l == 0) {
       if (nit_out) nit_out[b] = kiter;
       if (nfev_out) nfev_out[b] = nfev;
@@ -1713,7 +1741,7 @@ __device__ __forceinline__ void bfgs_iterate_2l(const typename Small<NQ, ALDS>::
 #endif
 template <int NQ, bool ALDS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QT_BFGS_WAVES))) k_mle_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B, int max_iter,
-                                                  double gtol, double* __restrict__ rho, int32_t* __restrict__ nit_out,
+                                                  double gtol, EstOut rho, int32_t* __restrict__ nit_out,
                                                   int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,
                                                   int32_t* __restrict__ status_out, const double* __restrict__ ws_x,
                                                   const double* __restrict__ ws_g, const double* __restrict__ ws_f,
@@ -1749,7 +1777,7 @@ constexpr int kFusedLdsPairs = 24;  // (s, y) pairs of k_mle_fused<3> kept in LD
 // loop.  Saves the second launch (2.5-4 us when nothing iterates, ~10 % of a 1000-trial step).
 template <int NQ, bool ALDS>
 __device__ __forceinline__ void mle_fused_body(const PovmView& pv, const int64_t* __restrict__ counts, int B, int init,
-                                               int max_iter, double gtol, double* __restrict__ rho,
+                                               int max_iter, double gtol, EstOut rho,
                                                int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
                                                double* __restrict__ fun_out, int32_t* __restrict__ status_out,
                                                double* __restrict__ pairs) {
@@ -1789,6 +1817,7 @@ __device__ __forceinline__ void mle_fused_body(const PovmView& pv, const int64_t
   const double gnorm = gmax<G>(fabs(gk));
   QT_STAMP(9);
   const bool iterate = live && shots_ok && ok && (gnorm > gtol) && (0 < max_iter);
+  S::emit(c, rho, b, live && !iterate, rho_l);  // (trials that iterate are written at the end of the loop)
   if (!iterate) {
     int status = 0;
     if (!shots_ok) status = 5;
@@ -1799,9 +1828,6 @@ __device__ __forceinline__ void mle_fused_body(const PovmView& pv, const int64_t
       else if (gnorm != gnorm || fk != fk || xn != xn) status = 4;
     }
     if (live) {
-      double* out = rho + ((size_t)b * D + c.l) * 2;
-      out[0] = rho_l.re;
-      out[1] = rho_l.im;
       if (c.l == 0) {
         if (nit_out) nit_out[b] = 0;
         if (nfev_out) nfev_out[b] = ok ? 1 : 0;
@@ -1831,14 +1857,14 @@ __device__ __forceinline__ void mle_fused_body(const PovmView& pv, const int64_t
 // 'lin'-start launches (bench.py's timed steps) and not a mixture with the iterating side measurements.
 template <int NQ, bool ALDS>
 __global__ void __launch_bounds__(256) k_mle_fused(PovmView pv, const int64_t* __restrict__ counts, int B, int max_iter,
-                                                   double gtol, double* __restrict__ rho, int32_t* __restrict__ nit_out,
+                                                   double gtol, EstOut rho, int32_t* __restrict__ nit_out,
                                                    int32_t* __restrict__ nfev_out, double* __restrict__ fun_out,
                                                    int32_t* __restrict__ status_out, double* __restrict__ pairs) {
   mle_fused_body<NQ, ALDS>(pv, counts, B, 0, max_iter, gtol, rho, nit_out, nfev_out, fun_out, status_out, pairs);
 }
 template <int NQ, bool ALDS>
 __global__ void __launch_bounds__(256) k_mle_fused_mixed(PovmView pv, const int64_t* __restrict__ counts, int B,
-                                                         int max_iter, double gtol, double* __restrict__ rho,
+                                                         int max_iter, double gtol, EstOut rho,
                                                          int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
                                                          double* __restrict__ fun_out, int32_t* __restrict__ status_out,
                                                          double* __restrict__ pairs) {

@@ -96,7 +96,7 @@ struct qt_handle {
   DevBuf pr_T, pr_P1, pr_P1T, pr_wrow, pr_rmap, pr_rinv, pr_fwd, pr_bwd, pr_aug;
   qt::ProductView prod{};
   // staging for host-pointer calls
-  DevBuf in0, in1, out0, out1, out2, out3, out4, proc_aug, proc_ws;
+  DevBuf in0, in1, out0, out1, out2, out3, out4, out5, proc_aug, proc_ws;
   // MLE hand-off between k_mle_start and k_mle_bfgs
   DevBuf ws_x, ws_g, ws_f, ws_act;
   // BFGS (s, y) history of the n >= 4 kernels (max_iter x 2 D doubles per trial of a chunk)
@@ -143,7 +143,11 @@ struct DeviceScope {
 #define QT_ENTER(h)                                                                                          \
   if (!(h)) return fail(QT_ERR_ARG, "null handle");                                                          \
   DeviceScope qt_scope_((h)->device);                                                                        \
-  if (qt_scope_.err != hipSuccess) return fail(QT_ERR_HIP, "hipSetDevice(%d): %s", (h)->device, hipGetErrorString(qt_scope_.err))
+  if (qt_scope_.err != hipSuccess) return fail(QT_ERR_HIP, "hipSetDevice(%d): %s", (h)->device, hipGetErrorString(qt_scope_.err)); \
+  /* outputs a FAILED host-pointer call left parked in the mailbox must never be copied into that caller's (possibly */   \
+  /* freed) arrays by the next call's drain: a successful call has drained before it returned */                          \
+  (h)->mail_pending.clear();                                                                                               \
+  (h)->mail_used = 0
 
 inline int grid_for(size_t total, int block = 256, int cap = 8192) {
   size_t g = (total + block - 1) / block;
@@ -266,7 +270,9 @@ constexpr size_t kLdsLimit = 160 * 1024;  // LDS per CU on gfx950; one workgroup
 // Measured (profiles/round1_v3_*): a lone wave per SIMD pays ~7-10 ns of issue per LDS read, more than
 // for a global load that lands asynchronously, and the image costs occupancy at large batch: the L2
 // streaming variant is faster in both regimes, so the image variant is kept but not selected.
-constexpr bool kPreferLdsImage = false;
+#ifdef QT_PREFER_LDS_IMAGE
+constexpr bool kPreferLdsImage = true;
+#endif
 
 // Launch KERNEL<NQ, ALDS> for the handle's n: the LDS-image variant when image + scratch fit in
 // 160 KB, else the variant that streams the operand from L2.  ARGS is the parenthesised argument list.
@@ -289,6 +295,7 @@ int allow_big_lds(K kernel, size_t bytes) {
     hipLaunchKernelGGL((KERNEL<NQV, ALDSV>), dim3(grid_), dim3(S_::NT), lds_, h->stream, QT_UNPACK ARGS); \
   } while (0)
 #define QT_UNPACK(...) __VA_ARGS__
+#ifdef QT_PREFER_LDS_IMAGE  /* the measured-slower variant: instantiated only on request (a third of the build time) */
 #define QT_LAUNCH_N(KERNEL, NQV, M_, B_, ARGS)                          \
   do {                                                                  \
     if (kPreferLdsImage && qt::Small<NQV, true>::lds_bytes(M_, h->prod.enabled ? h->prod.R1 : 0) <= kLdsLimit) \
@@ -296,6 +303,9 @@ int allow_big_lds(K kernel, size_t bytes) {
     else                                                                \
       QT_LAUNCH_ONE(KERNEL, NQV, false, M_, B_, ARGS);                  \
   } while (0)
+#else
+#define QT_LAUNCH_N(KERNEL, NQV, M_, B_, ARGS) QT_LAUNCH_ONE(KERNEL, NQV, false, M_, B_, ARGS)
+#endif
 #define QT_LAUNCH_SMALL(KERNEL, M_, B_, ARGS)                                                               \
   switch (h->nq) {                                                                                          \
     case 1: QT_LAUNCH_N(KERNEL, 1, M_, B_, ARGS); break;                                                    \
@@ -447,7 +457,7 @@ void qt_destroy(qt_handle_t* h) {
   for (DevBuf* b : {&h->pr_T, &h->pr_P1, &h->pr_P1T, &h->pr_wrow, &h->pr_rmap, &h->pr_rinv, &h->pr_fwd, &h->pr_bwd, &h->pr_aug})
     b->release();
   for (DevBuf* b : {&h->A, &h->AT, &h->Aw, &h->AwT, &h->Pinv, &h->PinvT, &h->Ns, &h->aug, &h->info, &h->kron_dig, &h->in0, &h->in1,
-                    &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->proc_aug, &h->proc_ws, &h->ws_x, &h->ws_g, &h->ws_f,
+                    &h->out0, &h->out1, &h->out2, &h->out3, &h->out4, &h->out5, &h->proc_aug, &h->proc_ws, &h->ws_x, &h->ws_g, &h->ws_f,
                     &h->ws_act, &h->hess, &h->sort_alt, &h->sort_tmp})
     b->release();
   h->proc.release();
@@ -896,31 +906,50 @@ int qt_mat_from_bloch(qt_handle_t* h, const double* bloch, int B, double* mat, i
   return finish(h, flags);
 }
 
-int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, double* rho, double* bloch_out,
-                 int32_t* status, int flags) {
+// a6 + a7 (+ a16 when `dist` is asked for): one body behind qt_lin_batch and qt_lin_dist_batch
+static int lin_batch_impl(qt_handle_t* h, const int64_t* counts, int B, int physical, const double* centre, double* rho,
+                          double* dist, double* bloch_out, int32_t* status, int flags) {
   QT_ENTER(h);
   if (int r = need_povm(h)) return r;
-  if (B < 0 || (B > 0 && (!counts || !rho))) return fail(QT_ERR_ARG, "bad lin_batch arguments");
+  if (B < 0 || (B > 0 && (!counts || (!rho && !dist) || (dist && !centre)))) return fail(QT_ERR_ARG, "bad lin_batch arguments");
   if (B == 0) return 0;
   const int64_t* dc;
-  double *drho, *dbl;
+  const double* dcen = nullptr;
+  double *drho, *dbl, *ddist;
   int32_t* dst;
   const size_t nel = (size_t)B * h->D;
   if (int r = stage_in(h, h->in0, counts, (size_t)B * h->M, flags, &dc)) return r;
+  if (dist)
+    if (int r = stage_in(h, h->in1, centre, (size_t)h->D * 2, flags, &dcen)) return r;
   if (int r = stage_out(h, h->out0, rho, nel * 2, flags, &drho)) return r;
   if (int r = stage_out(h, h->out1, bloch_out, nel, flags, &dbl)) return r;
   if (int r = stage_out(h, h->out2, status, (size_t)B, flags, &dst)) return r;
+  if (int r = stage_out(h, h->out3, dist, (size_t)B, flags, &ddist)) return r;
+  const qt::EstOut eo{drho, dcen, ddist};
   if (h->nq >= 4) {
     if (int r = prepare_large(h, true)) return r;
-    QT_LAUNCH_LARGE(qt::k_lin_large, B, h->M, h->prod.R1, (h->view(), dc, B, physical, drho, dbl, dst));
+    QT_LAUNCH_LARGE(qt::k_lin_large, B, h->M, h->prod.R1, (h->view(), dc, B, physical, eo, dbl, dst));
   } else {
-    QT_LAUNCH_SMALL(qt::k_lin_batch, h->M, B, (h->view(), dc, B, physical, drho, dbl, dst));
+    QT_LAUNCH_SMALL(qt::k_lin_batch, h->M, B, (h->view(), dc, B, physical, eo, dbl, dst));
   }
   if (int r = fetch_out(h, drho, rho, nel * 2, flags)) return r;
   if (int r = fetch_out(h, dbl, bloch_out, nel, flags)) return r;
   if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
+  if (int r = fetch_out(h, ddist, dist, (size_t)B, flags)) return r;
   if (int r = finish(h, flags)) return r;
   return count_bad(status, B, flags);
+}
+
+int qt_lin_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, double* rho, double* bloch_out,
+                 int32_t* status, int flags) {
+  if (B > 0 && !rho) return fail(QT_ERR_ARG, "bad lin_batch arguments");
+  return lin_batch_impl(h, counts, B, physical, nullptr, rho, nullptr, bloch_out, status, flags);
+}
+
+int qt_lin_dist_batch(qt_handle_t* h, const int64_t* counts, int B, int physical, const double* centre, double* rho,
+                      double* dist, int32_t* status, int flags) {
+  if (B > 0 && (!dist || !centre)) return fail(QT_ERR_ARG, "bad lin_dist_batch arguments");
+  return lin_batch_impl(h, counts, B, physical, centre, rho, dist, nullptr, status, flags);
 }
 
 int qt_chol_param(qt_handle_t* h, const double* rho, int B, double* x, int32_t* status, int flags) {
@@ -1013,20 +1042,27 @@ int qt_mhmc_state(qt_handle_t* h, const int64_t* counts, int C, const double* x_
   return finish(h, flags);
 }
 
-int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol, double* rho,
-                 int32_t* nit, int32_t* nfev, double* fun, int32_t* status, int flags) {
+// a8-a10 (+ a16 when `dist` is asked for): one body behind qt_mle_batch and qt_mle_dist_batch
+static int mle_batch_impl(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol,
+                          const double* centre, double* rho, double* dist, int32_t* nit, int32_t* nfev, double* fun,
+                          int32_t* status, int flags) {
   QT_ENTER(h);
   if (int r = need_povm(h)) return r;
-  if (B < 0 || (B > 0 && (!counts || !rho))) return fail(QT_ERR_ARG, "bad mle_batch arguments");
+  if (B < 0 || (B > 0 && (!counts || (!rho && !dist) || (dist && !centre)))) return fail(QT_ERR_ARG, "bad mle_batch arguments");
   if (init != QT_INIT_LIN && init != QT_INIT_MIXED) return fail(QT_ERR_ARG, "init must be QT_INIT_LIN or QT_INIT_MIXED");
   if (max_iter < 0) return fail(QT_ERR_ARG, "max_iter < 0");
   if (B == 0) return 0;
   const int64_t* dc;
-  double *drho, *dfun;
+  const double* dcen = nullptr;
+  double *drho, *dfun, *ddist;
   int32_t *dnit, *dnfev, *dst;
   const size_t nel = (size_t)B * h->D;
   if (int r = stage_in(h, h->in0, counts, (size_t)B * h->M, flags, &dc)) return r;
+  if (dist)
+    if (int r = stage_in(h, h->in1, centre, (size_t)h->D * 2, flags, &dcen)) return r;
   if (int r = stage_out(h, h->out0, rho, nel * 2, flags, &drho)) return r;
+  if (int r = stage_out(h, h->out5, dist, (size_t)B, flags, &ddist)) return r;
+  const qt::EstOut eo{drho, dcen, ddist};
   if (int r = stage_out(h, h->out1, nit, (size_t)B, flags, &dnit)) return r;
   if (int r = stage_out(h, h->out2, nfev, (size_t)B, flags, &dnfev)) return r;
   if (int r = stage_out(h, h->out3, fun, (size_t)B, flags, &dfun)) return r;
@@ -1048,11 +1084,12 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
     int32_t* wact = h->ws_act.as<int32_t>();
     // start point + first evaluation of every trial; then the BFGS loop of those that iterate, chunk by chunk
     QT_LAUNCH_LARGE(qt::k_mle_large_start, B, h->M, h->prod.R1,
-                    (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+                    (h->view(), dc, B, init, max_iter, tol, eo, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
     for (int b0 = 0; b0 < B; b0 += chunk) {
       const int nb = (B - b0 < chunk) ? B - b0 : chunk;
       QT_LAUNCH_LARGE_X(qt::k_mle_large_bfgs, nb, h->M, h->prod.R1, max_iter,
-                        (h->view(), dc + (size_t)b0 * h->M, nb, max_iter, tol, drho + (size_t)b0 * h->D * 2,
+                        (h->view(), dc + (size_t)b0 * h->M, nb, max_iter, tol,
+                         qt::EstOut{drho ? drho + (size_t)b0 * h->D * 2 : nullptr, dcen, ddist ? ddist + b0 : nullptr},
                          dnit ? dnit + b0 : nullptr, dnfev ? dnfev + b0 : nullptr, dfun ? dfun + b0 : nullptr,
                          dst ? dst + b0 : nullptr, wx + (size_t)b0 * h->D, wg + (size_t)b0 * h->D, wf + b0, wact + b0,
                          h->hess.as<double>()));
@@ -1074,10 +1111,10 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
       }
       if (init == QT_INIT_LIN) {
         QT_LAUNCH_SMALL(qt::k_mle_fused, h->M, B,
-                        (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, h->hess.as<double>()));
+                        (h->view(), dc, B, max_iter, tol, eo, dnit, dnfev, dfun, dst, h->hess.as<double>()));
       } else {
         QT_LAUNCH_SMALL(qt::k_mle_fused_mixed, h->M, B,
-                        (h->view(), dc, B, max_iter, tol, drho, dnit, dnfev, dfun, dst, h->hess.as<double>()));
+                        (h->view(), dc, B, max_iter, tol, eo, dnit, dnfev, dfun, dst, h->hess.as<double>()));
       }
       h->lds_extra = 0;
     } else {
@@ -1088,7 +1125,7 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
       double *wx = h->ws_x.as<double>(), *wg = h->ws_g.as<double>(), *wf = h->ws_f.as<double>();
       int32_t* wact = h->ws_act.as<int32_t>();
       QT_LAUNCH_SMALL(qt::k_mle_start, h->M, B,
-                      (h->view(), dc, B, init, max_iter, tol, drho, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
+                      (h->view(), dc, B, init, max_iter, tol, eo, dnit, dnfev, dfun, dst, wx, wg, wf, wact));
       // BFGS history of the trials that iterate: 2 D doubles per iteration and trial (two-loop recursion), in
       // chunks of <= 4 GiB; rho_i, alpha_i and the parked line-search state in LDS
       int chunk = B;
@@ -1103,7 +1140,8 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
       for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (B - b0 < chunk) ? B - b0 : chunk;
         QT_LAUNCH_SMALL(qt::k_mle_bfgs, h->M, nb,
-                        (h->view(), dc + (size_t)b0 * h->M, nb, max_iter, tol, drho + (size_t)b0 * h->D * 2,
+                        (h->view(), dc + (size_t)b0 * h->M, nb, max_iter, tol,
+                         qt::EstOut{drho ? drho + (size_t)b0 * h->D * 2 : nullptr, dcen, ddist ? ddist + b0 : nullptr},
                          dnit ? dnit + b0 : nullptr, dnfev ? dnfev + b0 : nullptr, dfun ? dfun + b0 : nullptr,
                          dst ? dst + b0 : nullptr, wx + (size_t)b0 * h->D, wg + (size_t)b0 * h->D, wf + b0, wact + b0,
                          h->hess.as<double>()));
@@ -1116,8 +1154,22 @@ int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max
   if (int r = fetch_out(h, dnfev, nfev, (size_t)B, flags)) return r;
   if (int r = fetch_out(h, dfun, fun, (size_t)B, flags)) return r;
   if (int r = fetch_out(h, dst, status, (size_t)B, flags)) return r;
+  if (int r = fetch_out(h, ddist, dist, (size_t)B, flags)) return r;
   if (int r = finish(h, flags)) return r;
   return count_bad(status, B, flags);
+}
+
+int qt_mle_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol, double* rho,
+                 int32_t* nit, int32_t* nfev, double* fun, int32_t* status, int flags) {
+  if (B > 0 && !rho) return fail(QT_ERR_ARG, "bad mle_batch arguments");
+  return mle_batch_impl(h, counts, B, init, max_iter, tol, nullptr, rho, nullptr, nit, nfev, fun, status, flags);
+}
+
+int qt_mle_dist_batch(qt_handle_t* h, const int64_t* counts, int B, int init, int max_iter, double tol,
+                      const double* centre, double* rho, double* dist, int32_t* nit, int32_t* nfev, double* fun,
+                      int32_t* status, int flags) {
+  if (B > 0 && (!dist || !centre)) return fail(QT_ERR_ARG, "bad mle_dist_batch arguments");
+  return mle_batch_impl(h, counts, B, init, max_iter, tol, centre, rho, dist, nit, nfev, fun, status, flags);
 }
 
 int qt_hs_dist_batch(qt_handle_t* h, const double* rho, const double* centre, int B, double* dist, int flags) {
@@ -1195,6 +1247,139 @@ int qt_sorted_quantiles(qt_handle_t* h, const double* sorted, long long n, const
   return finish(h, flags);
 }
 
+// ---- a16 over several ranks: the order statistics interp1d needs from a sample whose sorted shards live on N ranks
+// (kernels and the argument in qt_ops.h; the two all-gathers in between are quantpy_amd/distributed.py's) -----------------
+int qt_select_splitters(qt_handle_t* h, const double* sorted, long long n, long long stride, int P, double* splitters,
+                        int flags) {
+  QT_ENTER(h);
+  if (n < 0 || stride < 1 || P < 1 || (n > 0 && !sorted) || !splitters) return fail(QT_ERR_ARG, "bad select_splitters arguments");
+  const double* ds;
+  double* dout;
+  if (int r = stage_in(h, h->in0, sorted, (size_t)(n > 0 ? n : 1), n > 0 ? flags : QT_DEVICE_PTR, &ds)) return r;
+  if (int r = stage_out(h, h->out0, splitters, (size_t)P, flags, &dout)) return r;
+  hipLaunchKernelGGL(qt::k_select_splitters, dim3((P + 255) / 256), dim3(256), 0, h->stream, ds, n, stride, P, dout);
+  if (int r = fetch_out(h, dout, splitters, (size_t)P, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_select_bracket(qt_handle_t* h, const double* splitters, int N, int P, const int64_t* sizes, long long stride,
+                      long long n_total, const double* conf_levels, int L, uint64_t* lo_key, uint64_t* hi_key, int flags) {
+  QT_ENTER(h);
+  if (N < 1 || P < 1 || L < 1 || stride < 1 || n_total < 0 || !splitters || !sizes || !conf_levels || !lo_key || !hi_key)
+    return fail(QT_ERR_ARG, "bad select_bracket arguments");
+  const double *dspl, *dq;
+  const int64_t* dsz;
+  uint64_t *dlo, *dhi;
+  if (int r = stage_in(h, h->in0, splitters, (size_t)N * P, flags, &dspl)) return r;
+  if (int r = stage_in(h, h->in1, sizes, (size_t)N, flags, &dsz)) return r;
+  if (int r = stage_in(h, h->out2, conf_levels, (size_t)L, flags, &dq)) return r;
+  if (int r = stage_out(h, h->out0, lo_key, (size_t)L, flags, &dlo)) return r;
+  if (int r = stage_out(h, h->out1, hi_key, (size_t)L, flags, &dhi)) return r;
+  hipLaunchKernelGGL(qt::k_select_init, dim3((L + 255) / 256), dim3(256), 0, h->stream,
+                     reinterpret_cast<unsigned long long*>(dlo), reinterpret_cast<unsigned long long*>(dhi), L);
+  hipLaunchKernelGGL(qt::k_select_bracket, dim3((unsigned)(((size_t)N * P + 255) / 256)), dim3(256), 0, h->stream, dspl, N, P,
+                     reinterpret_cast<const long long*>(dsz), stride, n_total, dq, L,
+                     reinterpret_cast<unsigned long long*>(dlo), reinterpret_cast<unsigned long long*>(dhi));
+  if (int r = fetch_out(h, (const uint64_t*)dlo, lo_key, (size_t)L, flags)) return r;
+  if (int r = fetch_out(h, (const uint64_t*)dhi, hi_key, (size_t)L, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_select_window(qt_handle_t* h, const double* sorted, long long n, const uint64_t* lo_key, const uint64_t* hi_key, int L,
+                     int W, double* window, int flags) {
+  QT_ENTER(h);
+  if (n < 0 || L < 1 || W < 1 || (n > 0 && !sorted) || !lo_key || !hi_key || !window)
+    return fail(QT_ERR_ARG, "bad select_window arguments");
+  const double* ds;
+  const uint64_t *dlo, *dhi;
+  double* dwin;
+  const size_t wn = (size_t)L * (2 + W);
+  if (int r = stage_in(h, h->in0, sorted, (size_t)(n > 0 ? n : 1), n > 0 ? flags : QT_DEVICE_PTR, &ds)) return r;
+  if (int r = stage_in(h, h->in1, lo_key, (size_t)L, flags, &dlo)) return r;
+  if (int r = stage_in(h, h->out2, hi_key, (size_t)L, flags, &dhi)) return r;
+  if (int r = stage_out(h, h->out0, window, wn, flags, &dwin)) return r;
+  hipLaunchKernelGGL(qt::k_select_window, dim3(L), dim3(256), 0, h->stream, ds, n,
+                     reinterpret_cast<const unsigned long long*>(dlo), reinterpret_cast<const unsigned long long*>(dhi), W, dwin);
+  if (int r = fetch_out(h, dwin, window, wn, flags)) return r;
+  return finish(h, flags);
+}
+
+int qt_select_finish(qt_handle_t* h, const double* windows, int N, int L, int W, long long n_total, const double* conf_levels,
+                     double* out, int32_t* overflow, int flags) {
+  QT_ENTER(h);
+  if (N < 1 || L < 1 || W < 1 || n_total < 1 || !windows || !conf_levels || !out || !overflow)
+    return fail(QT_ERR_ARG, "bad select_finish arguments");
+  const double *dw, *dq;
+  double* dout;
+  int32_t* dfl;
+  const size_t wn = (size_t)N * L * (2 + W);
+  if (int r = stage_in(h, h->in0, windows, wn, flags, &dw)) return r;
+  if (int r = stage_in(h, h->in1, conf_levels, (size_t)L, flags, &dq)) return r;
+  if (int r = stage_out(h, h->out0, out, (size_t)L, flags, &dout)) return r;
+  if (int r = stage_out(h, h->out1, overflow, 1, flags, &dfl)) return r;
+  HIPCHK(hipMemsetAsync(dfl, 0, sizeof(int32_t), h->stream));
+  size_t cap = (size_t)N * W;
+  if (cap > 16000) cap = 16000;  // 128 KB of LDS; a larger union raises the overflow flag (heavy ties: take the merge path)
+  const size_t lds = cap * sizeof(double) + ((size_t)N + 2) * sizeof(int);
+  if (int r = allow_big_lds(qt::k_select_finish, lds)) return r;
+  hipLaunchKernelGGL(qt::k_select_finish, dim3(L), dim3(1024), lds, h->stream, dw, N, L, W, (int)cap, n_total, dq, dout,
+                     reinterpret_cast<int*>(dfl));
+  if (int r = fetch_out(h, dout, out, (size_t)L, flags)) return r;
+  if (int r = fetch_out(h, dfl, overflow, 1, flags)) return r;
+  return finish(h, flags);
+}
+
+// R sorted runs, concatenated in `runs` (lengths: a HOST array, the launch geometry depends on them) -> out sorted.
+// Pairwise merge-path passes, ceil(log2 R) of them, ping-ponging between out and a scratch buffer.
+int qt_merge_sorted(qt_handle_t* h, const double* runs, const int64_t* run_lengths, int R, double* out, int flags) {
+  QT_ENTER(h);
+  if (R < 1 || !run_lengths || !out) return fail(QT_ERR_ARG, "bad merge_sorted arguments");
+  long long n = 0;
+  for (int r = 0; r < R; ++r) {
+    if (run_lengths[r] < 0) return fail(QT_ERR_ARG, "negative run length");
+    n += run_lengths[r];
+  }
+  if (n == 0) return 0;
+  if (!runs) return fail(QT_ERR_ARG, "bad merge_sorted arguments");
+  const double* din;
+  double* dout;
+  if (int r = stage_in(h, h->in0, runs, (size_t)n, flags, &din)) return r;
+  if (int r = stage_out(h, h->out0, out, (size_t)n, flags, &dout)) return r;
+  std::vector<long long> len(run_lengths, run_lengths + R);
+  int passes = 0;
+  for (int m = R; m > 1; m = (m + 1) / 2) ++passes;
+  if (passes == 0) {
+    if (din != dout) HIPCHK(hipMemcpyAsync(dout, din, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    HIPCHK(h->sort_alt.ensure((size_t)n * sizeof(double)));
+    double* alt = h->sort_alt.as<double>();
+    // the last pass must land in dout: choose the first destination accordingly (the source of pass 0 is din, read-only)
+    const double* src = din;
+    double* dst = (passes & 1) ? dout : alt;
+    if (dst == src) return fail(QT_ERR_ARG, "qt_merge_sorted: out must not alias runs");
+    constexpr int TILE = 8;
+    for (int p = 0; p < passes; ++p) {
+      std::vector<long long> next;
+      long long at = 0;
+      for (size_t r = 0; r < len.size(); r += 2) {
+        const long long na = len[r], nb = r + 1 < len.size() ? len[r + 1] : 0;
+        if (na + nb > 0) {
+          const long long threads = (na + nb + TILE - 1) / TILE;
+          hipLaunchKernelGGL(qt::k_merge_runs<TILE>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, src + at,
+                             na, src + at + na, nb, dst + at);
+        }
+        next.push_back(na + nb);
+        at += na + nb;
+      }
+      len.swap(next);
+      src = dst;
+      dst = (dst == dout) ? alt : dout;
+    }
+  }
+  if (int r = fetch_out(h, (const double*)dout, out, (size_t)n, flags)) return r;
+  return finish(h, flags);
+}
+
 // ---- a4 / a12 / a16 host side: state.py:109-114, the draws of experiment() (qt_sampler.h) ---------
 static int check_pvals(int period, int K, const int64_t* n, const double* pvals);
 
@@ -1249,9 +1434,17 @@ int qt_device_multinomial(qt_handle_t* h, uint64_t seed, uint64_t first_row, lon
   if (int r = stage_in(h, h->in0, n, (size_t)period, flags, &dn)) return r;
   if (int r = stage_in(h, h->in1, pvals, (size_t)period * K, flags, &dp)) return r;
   if (int r = stage_out(h, h->out0, out, (size_t)rows * K, flags, &dout)) return r;
-  const long long span = 64LL * period, threads = (rows + span - 1) / span * span;  // whole 64 x period blocks of rows
-  hipLaunchKernelGGL(qt_sampler::k_multinomial_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, seed,
-                     first_row, rows, period, dn, dp, K, dout);
+  // whole 64 x period blocks of rows per launch (a wavefront = one setting of 64 consecutive resamples); a launch covers at
+  // most 2^30 threads -- HIP rejects grids of 2^32 threads and more -- so larger tables go out in chunks, each keyed by its
+  // own first row: the table depends on (seed, global row) only
+  const long long span = 64LL * period;
+  const long long chunk_rows = (span >= (1LL << 30)) ? span : ((1LL << 30) / span) * span;
+  for (long long r0 = 0; r0 < rows; r0 += chunk_rows) {
+    const long long nr = rows - r0 < chunk_rows ? rows - r0 : chunk_rows;
+    const long long threads = (nr + span - 1) / span * span;
+    hipLaunchKernelGGL(qt_sampler::k_multinomial_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, seed,
+                       first_row + (uint64_t)r0, nr, period, dn, dp, K, dout + (size_t)r0 * K);
+  }
   if (int r = fetch_out(h, (const int64_t*)dout, out, (size_t)rows * K, flags)) return r;
   return finish(h, flags);
 }

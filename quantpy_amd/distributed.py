@@ -105,6 +105,231 @@ def allgather_device(local, n_total):
     return torch.cat([out[r * width: r * width + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
 
 
+def allgather_equal(x):
+    """Stack the ranks' equally shaped tensors / arrays along a new first axis: (N, *x.shape) on every rank.  torch CUDA
+    tensors travel as ONE RCCL all-gather on torch's current stream (`nccl` group) or through the host (`gloo`);
+    NumPy arrays come back as NumPy arrays."""
+    import torch
+
+    dist = _dist()
+    is_np = isinstance(x, np.ndarray)
+    if dist is None or dist.get_world_size() == 1:
+        return x[None]
+    ws = dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        t = torch.from_numpy(np.ascontiguousarray(x)).to(_comm_device()) if is_np else x.contiguous()
+        out = torch.empty((ws,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.view(-1))
+        return out.cpu().numpy() if is_np else out
+    t = torch.from_numpy(np.ascontiguousarray(x)) if is_np else x.detach().cpu().contiguous()
+    parts = [torch.empty_like(t) for _ in range(ws)]
+    dist.all_gather(parts, t)
+    out = torch.stack(parts)
+    return out.numpy() if is_np else out.to(x.device)
+
+
+# ---- interval.py:610-612 for a sample whose shards stay on their ranks --------------------------------------------------
+def _sort_keys(a):
+    """Order-preserving uint64 keys of float64 values: the order of np.sort / of the device radix sort (NaN last)."""
+    b = np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+    return np.where(b >> np.uint64(63), ~b, b | np.uint64(1 << 63))
+
+
+def interp_cell(n, q):
+    """The cell of np.linspace(0, 1, n) that scipy's interp1d evaluates q in: (lo, x_lo, x_hi) with lo + 1 =
+    searchsorted(grid, q, 'left') clipped to [1, n - 1] (the same walk as the device's interp_cell, qt_ops.h)."""
+    step = 1.0 / (n - 1)
+
+    def grid(i):
+        return 1.0 if i == n - 1 else i * step
+
+    hi = min(int(q * (n - 1)), n - 1)
+    while hi > 0 and grid(hi - 1) >= q:
+        hi -= 1
+    while hi < n - 1 and grid(hi) < q:
+        hi += 1
+    hi = max(hi, 1)
+    return hi - 1, grid(hi - 1), grid(hi)
+
+
+def selection_plan(n_total, world_size, n_levels):
+    """(stride, n_splitters, window_width) of the two-exchange selection, or None when gathering the sorted shards is
+    the smaller exchange.  Between two consecutive merged splitters a rank holds fewer than `stride` values and the
+    bracket of a level spans at most 2 N + 2 splitters, hence the window bound (2 N + 3) * stride (heavy ties aside:
+    those raise the overflow flag and take the gather path)."""
+    n_max = -(-n_total // world_size)
+    if n_max < 1 or n_levels < 1:
+        return None
+    factor = 2 * world_size + 3
+    p = int(round((n_levels * factor * n_max) ** 0.5))
+    p = max(16, min(p, 8192, n_max))
+    stride = -(-n_max // p)
+    p = -(-n_max // stride)
+    width = min(factor * stride, n_max)
+    if world_size * (p + n_levels * (2 + width)) >= n_total or n_levels > 64:
+        return None
+    return stride, p, width
+
+
+class ShardedSample:
+    """A sample of `n_total` float64 values of which this rank holds its `shard_bounds(n_total)` slice -- the bootstrap
+    distances of interval.py:598-609 where they were computed.  `quantiles(levels)` is
+    `interp1d(np.linspace(0, 1, n), np.sort(sample))(levels)` (interval.py:610-612) evaluated WITHOUT assembling the
+    sample: each rank sorts its shard, then either the two small exchanges of the distributed selection (few levels;
+    kernels in csrc/qt_ops.h, argument in include/qtomo.h) or one gather of the sorted shards and a merge.  Collective:
+    every rank calls the same methods in the same order.
+
+    `local` is a NumPy array (host arithmetic below, the form the gloo tests run) or a float64 torch CUDA tensor (then
+    `engine` does every step on the GPU and only the L results cross to the host).  The shard is sorted in place."""
+
+    def __init__(self, local, n_total, engine=None):
+        self.n_total = int(n_total)
+        self.rank, self.world = world()
+        self.sizes = np.array([hi - lo for lo, hi in (shard_bounds(self.n_total, r, self.world) for r in range(self.world))],
+                              dtype=np.int64)
+        self.device = not isinstance(local, np.ndarray)
+        if local.shape[0] != self.sizes[self.rank]:
+            raise ValueError(f"rank {self.rank} holds {local.shape[0]} values, its shard of {self.n_total} is {self.sizes[self.rank]}")
+        self.engine = engine
+        if self.device:
+            if engine is None:
+                raise ValueError("a device-resident shard needs the engine that sorts and selects on it")
+            self.local = engine.sort_dev(local) if local.numel() > 1 else local
+        else:
+            self.local = np.sort(np.ascontiguousarray(local, dtype=np.float64))
+        self._full = None
+        self.last_path = None  # 'local' | 'selection' | 'gather': what the last quantiles() call did (tests, bench)
+
+    # -- the whole sorted sample on every rank (one all-gather of the sorted shards + a merge) ---------------------------
+    def gather_sorted(self):
+        if self._full is not None:
+            return self._full
+        if self.world == 1:
+            self._full = self.local
+            return self._full
+        width = int(self.sizes.max())
+        if self.device:
+            import torch
+
+            buf = self.local
+            if buf.shape[0] != width:
+                buf = torch.empty(width, dtype=torch.float64, device=self.local.device)
+                buf[: self.local.shape[0]] = self.local
+            runs = allgather_equal(buf)  # (N, width)
+            if int(self.sizes.min()) != width:
+                runs = torch.cat([runs[r, : int(self.sizes[r])] for r in range(self.world)])
+            self._full = self.engine.merge_sorted(runs.reshape(-1), self.sizes)
+        else:
+            buf = np.full(width, np.nan)
+            buf[: self.local.shape[0]] = self.local
+            runs = allgather_equal(buf)
+            self._full = np.sort(np.concatenate([runs[r, : int(self.sizes[r])] for r in range(self.world)]), kind="stable")
+        return self._full
+
+    def _quantiles_of(self, srt, levels):
+        if self.device:
+            return self.engine.quantiles_of_sorted(srt, levels)
+        n = len(srt)
+        if n == 1:
+            return np.full(len(levels), srt[0])
+        out = np.empty(len(levels))
+        for t, q in enumerate(levels):
+            lo, xl, xh = interp_cell(n, float(q))
+            out[t] = (srt[lo + 1] - srt[lo]) / (xh - xl) * (q - xl) + srt[lo]
+        return out
+
+    def quantiles(self, levels):
+        levels = np.ascontiguousarray(np.atleast_1d(levels), dtype=np.float64)
+        if levels.size and (levels.min() < 0 or levels.max() > 1 or np.isnan(levels).any()):
+            raise ValueError("A value in x_new is outside the interpolation range.")
+        if self.n_total < 1:
+            raise ValueError("empty sample")
+        if levels.size == 0:
+            return np.empty(0)
+        if self.world == 1 or self._full is not None:
+            self.last_path = "local"
+            return self._quantiles_of(self.gather_sorted(), levels)
+        plan = selection_plan(self.n_total, self.world, levels.size)
+        if plan is not None:
+            out = self._select_device(levels, *plan) if self.device else self._select_host(levels, *plan)
+            if out is not None:
+                self.last_path = "selection"
+                return out
+        self.last_path = "gather"
+        return self._quantiles_of(self.gather_sorted(), levels)
+
+    __call__ = quantiles
+
+    # -- distributed selection on the GPU: four launches, two small all-gathers, one read-back -----------------------------
+    def _select_device(self, levels, stride, n_split, width):
+        import torch
+
+        eng, dev = self.engine, self.local.device
+        q = torch.from_numpy(levels).to(dev)
+        spl = torch.empty(n_split, dtype=torch.float64, device=dev)
+        eng.select_splitters(self.local, stride, n_split, spl)
+        all_spl = allgather_equal(spl)
+        sizes = torch.from_numpy(self.sizes).to(dev)
+        lo = torch.empty(levels.size, dtype=torch.int64, device=dev)
+        hi = torch.empty(levels.size, dtype=torch.int64, device=dev)
+        eng.select_bracket(all_spl, sizes, stride, self.n_total, q, lo, hi)
+        win = torch.empty((levels.size, 2 + width), dtype=torch.float64, device=dev)
+        eng.select_window(self.local, lo, hi, width, win)
+        all_win = allgather_equal(win)
+        res = torch.empty(levels.size + 1, dtype=torch.float64, device=dev)
+        flag = torch.zeros(2, dtype=torch.int32, device=dev)
+        eng.select_finish(all_win, self.n_total, q, res[: levels.size], flag)
+        eng.sync()
+        if int(flag[0].item()) != 0:  # the same on every rank (computed from the gathered windows): take the gather path
+            return None
+        return res[: levels.size].cpu().numpy()
+
+    # -- the same four steps in NumPy (host-resident shards: the reference's own distances, the gloo tests) ---------------
+    def _select_host(self, levels, stride, n_split, width):
+        n, nr = self.n_total, self.world
+        keys = _sort_keys(self.local)
+        pad = np.uint64(0xFFFFFFFFFFFFFFFF)
+        spl = np.full(n_split, pad, dtype=np.uint64)
+        take = keys[::stride]
+        spl[: len(take)] = take
+        all_spl = allgather_equal(spl.view(np.int64)).view(np.uint64)  # (N, P), bit patterns
+        valid = [int(-(-self.sizes[r] // stride)) for r in range(nr)]
+        cand = np.concatenate([all_spl[r, : valid[r]] for r in range(nr)])
+        up = np.zeros(len(cand), dtype=np.int64)
+        low = np.zeros(len(cand), dtype=np.int64)
+        for r in range(nr):
+            cnt = np.searchsorted(all_spl[r, : valid[r]], cand, side="right").astype(np.int64)
+            up += np.minimum(self.sizes[r], cnt * stride)
+            low += np.where(cnt > 0, (cnt - 1) * stride + 1, 0)
+        win = np.zeros((levels.size, 2 + width))
+        cells = []
+        for t, qv in enumerate(levels):
+            k0 = interp_cell(n, float(qv))[0] if n >= 2 else 0
+            cells.append(k0)
+            sel_lo = cand[up <= k0]
+            sel_hi = cand[low >= k0 + 2] if n >= 2 else cand[:0]
+            below = int(np.searchsorted(keys, sel_lo.max(), side="right")) if sel_lo.size else 0
+            upto = int(np.searchsorted(keys, sel_hi.min(), side="right")) if sel_hi.size else len(keys)
+            w = upto - below
+            win[t, 0], win[t, 1] = below, w
+            win[t, 2: 2 + min(w, width)] = self.local[below: below + min(w, width)]
+        all_win = allgather_equal(win)  # (N, L, 2 + W)
+        if (all_win[:, :, 1] > width).any():
+            return None
+        out = np.empty(levels.size)
+        for t, qv in enumerate(levels):
+            below = int(all_win[:, t, 0].sum())
+            union = np.sort(np.concatenate([all_win[r, t, 2: 2 + int(all_win[r, t, 1])] for r in range(nr)]), kind="stable")
+            k0 = cells[t]
+            if n == 1:
+                out[t] = union[k0 - below]
+                continue
+            _, xl, xh = interp_cell(n, float(qv))
+            yl, yh = union[k0 - below], union[k0 + 1 - below]
+            out[t] = (yh - yl) / (xh - xl) * (qv - xl) + yl
+        return out
+
+
 def sharded_map(items, fn):
     """Apply `fn(items[lo:hi]) -> 1-D float64 array` to this rank's slice and all-gather."""
     n = len(items)

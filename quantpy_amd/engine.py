@@ -31,6 +31,16 @@ def _check_shots(status):
                          "tomograph / set_povm call)")
 
 
+def _torch_stream_ptr(device):
+    """hipStream_t of torch's current stream on `device`, as an integer (0 = the legacy default stream)."""
+    import torch
+
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return int(raw(device))
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
 class EngineError(RuntimeError):
     def __init__(self, code, text):
         super().__init__(f"libqtomo error {code}: {text}")
@@ -68,31 +78,44 @@ def _i64(a):
     return np.ascontiguousarray(a)
 
 
+_DEFAULT_DEVICE = None  # (LOCAL_RANK string, device index): resolved once per process (see default_device)
+
+
 def default_device():
     """The device index an engine is created on when the caller names none: the process's own GPU.
-    `QTOMO_DEVICE` if set; else torch's current device once torch has initialised the GPU (one rank
-    per GPU: torch.cuda.set_device(local_rank) happened first); else `LOCAL_RANK` (torchrun) clamped
-    to the visible devices; else 0."""
+    `QTOMO_DEVICE` if set; else torch's current device when the caller has moved it off device 0
+    (`torch.cuda.set_device(local_rank)`: one rank per GPU); else `LOCAL_RANK` (torchrun) modulo the number of
+    VISIBLE devices (a launcher that masks each rank down to one GPU with HIP_VISIBLE_DEVICES leaves LOCAL_RANK = 3
+    pointing at device 0), resolved once per process -- so that torch initialising the GPU half-way through a run
+    (current device 0 by default) does not move a rank's engines onto GPU 0; else 0."""
+    global _DEFAULT_DEVICE
     env = os.environ.get("QTOMO_DEVICE")
     if env is not None:
         return int(env)
     torch = sys.modules.get("torch")
     if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
-        return int(torch.cuda.current_device())
+        cur = int(torch.cuda.current_device())
+        if cur != 0 or os.environ.get("LOCAL_RANK") is None:
+            return cur
     lr = os.environ.get("LOCAL_RANK")
-    if lr is not None:
-        return int(lr)
-    return 0
+    if _DEFAULT_DEVICE is None or _DEFAULT_DEVICE[0] != lr:
+        if lr is None:
+            _DEFAULT_DEVICE = (lr, 0)
+        else:
+            n = _capi.load().qt_device_count()
+            _DEFAULT_DEVICE = (lr, int(lr) % n if n > 0 else int(lr))
+    return _DEFAULT_DEVICE[1]
 
 
 class Engine:
     """Owns a qt_handle (device buffers, stream, cached POVM operators) for `n_qubits`.
 
     Host-pointer (NumPy) calls are synchronous.  Device-pointer (`*_dev`, torch tensors) calls are
-    asynchronous on the handle's stream; the first of them binds the handle to torch's current
-    stream (`bind_torch_stream`), so that they are ordered with the torch work that produced their
-    inputs and consumes their outputs.  `stream="own"` keeps a private non-blocking stream instead
-    (the caller then orders producers / consumers itself: `sync()`)."""
+    asynchronous on the handle's stream; each of them first makes sure the handle runs on torch's
+    CURRENT stream of its device (re-binding when the caller has switched streams since the last call),
+    so that they are ordered with the torch work that produced their inputs and consumes their
+    outputs.  `stream="own"` keeps a private non-blocking stream instead (the caller then orders
+    producers / consumers itself: `sync()`); an explicit `set_stream()` pins the handle likewise."""
 
     def __init__(self, n_qubits, device=None, stream="torch"):
         self.lib = _capi.load()
@@ -105,8 +128,8 @@ class Engine:
             raise _capi.EngineUnavailable(_capi.last_error())
         self._povm_key = None
         self._proc_key = None
-        self._stream_policy = stream
-        self._stream_bound = stream == "own"
+        self._stream_policy = stream  # "torch": follow torch's current stream; "own" / "pinned": leave the handle's stream alone
+        self._bound_ptr = None        # the torch stream pointer the handle was last bound to
         self.S = self.K = self.M = 0
 
     def close(self):
@@ -130,20 +153,28 @@ class Engine:
         self._chk(self.lib.qt_sync(self._h))
 
     def set_stream(self, stream_ptr):
-        """Bind to a hipStream_t given as an integer; 0 / None = a private stream, 1 = the legacy default stream."""
+        """Pin the handle to a hipStream_t given as an integer; 0 / None = a private stream, 1 = the legacy default
+        stream.  Device-pointer calls stop following torch's current stream (`follow_torch_stream()` resumes that)."""
         self._chk(self.lib.qt_set_stream(self._h, ctypes.c_void_p(stream_ptr or None)))
-        self._stream_bound = True
+        self._stream_policy = "pinned"
+        self._bound_ptr = None
+
+    def follow_torch_stream(self):
+        self._stream_policy = "torch"
+        self._bound_ptr = None
 
     def bind_torch_stream(self):
         """Run this engine's work on torch's current stream of its device (stream 0 = the legacy default
-        stream).  Called by the first device-pointer call; call it again after switching torch streams."""
-        import torch
-
-        ptr = int(torch.cuda.current_stream(self.device).cuda_stream)
-        self.set_stream(ptr if ptr else _capi.QT_STREAM_LEGACY)
+        stream).  Every device-pointer call does this by itself while the policy is "torch"."""
+        ptr = _torch_stream_ptr(self.device)
+        if ptr != self._bound_ptr:
+            self._chk(self.lib.qt_set_stream(self._h, ctypes.c_void_p(ptr if ptr else _capi.QT_STREAM_LEGACY)))
+            self._bound_ptr = ptr
 
     def _dev_call(self):
-        if not self._stream_bound:
+        # ADVICE r2: binding once was a silent race for a caller that switches torch streams between calls (the handle
+        # kept enqueueing on the old stream, unordered with the producers of its inputs).  One raw-pointer read per call.
+        if self._stream_policy == "torch":
             self.bind_torch_stream()
 
     def set_option(self, option, value):
@@ -392,6 +423,26 @@ class Engine:
         self._chk(self.lib.qt_lin_batch(self._h, _ptr(counts), counts.shape[0], int(bool(physical)), _ptr(rho),
                                         _ptr(bloch), _ptr(status), _capi.QT_DEVICE_PTR))
 
+    def lin_dist(self, counts, centre, physical=True):
+        """hs_dst(point_estimate('lin')(counts_b), centre) for every trial, in ONE pass (qt_lin_dist_batch: the
+        estimates themselves are not written).  counts (B, S, K) -> (B,) float64."""
+        c, _ = self._counts(counts)
+        b = c.shape[0]
+        cen = _c128(centre)
+        assert cen.shape == (self.d, self.d)
+        dist = np.empty(b)
+        status = np.zeros(b, dtype=np.int32)
+        self._chk(self.lib.qt_lin_dist_batch(self._h, _ptr(c), b, int(bool(physical)), _ptr(cen), None, _ptr(dist),
+                                             _ptr(status), _capi.QT_HOST_PTR))
+        _check_shots(status)
+        return dist
+
+    def lin_dist_dev(self, counts, centre, dist, physical=True, rho=None, status=None):
+        """device-pointer form: centre complex128 (d, d), dist float64 (B,) torch CUDA tensors; rho optional"""
+        self._dev_call()
+        self._chk(self.lib.qt_lin_dist_batch(self._h, _ptr(counts), counts.shape[0], int(bool(physical)), _ptr(centre),
+                                             _ptr(rho), _ptr(dist), _ptr(status), _capi.QT_DEVICE_PTR))
+
     # ---- a8 / a9 ----------------------------------------------------------------------------
     def chol_param(self, rho):
         rho = _c128(rho)
@@ -466,6 +517,31 @@ class Engine:
                                         float(tol), _ptr(rho), _ptr(nit), _ptr(nfev), _ptr(fun), _ptr(status),
                                         _capi.QT_DEVICE_PTR))
 
+    def mle_dist(self, counts, centre, init="lin", max_iter=100, tol=1e-3, return_info=False):
+        """hs_dst(point_estimate('mle')(counts_b), centre) for every trial in ONE pass (qt_mle_dist_batch)."""
+        if init not in ("lin", "mixed"):
+            raise ValueError("Invalid value for argument `init`")
+        c, _ = self._counts(counts)
+        b = c.shape[0]
+        cen = _c128(centre)
+        assert cen.shape == (self.d, self.d)
+        dist = np.empty(b)
+        nit = np.zeros(b, dtype=np.int32)
+        status = np.zeros(b, dtype=np.int32)
+        self._chk(self.lib.qt_mle_dist_batch(self._h, _ptr(c), b, _capi.QT_INIT_LIN if init == "lin" else _capi.QT_INIT_MIXED,
+                                             int(max_iter), float(tol), _ptr(cen), None, _ptr(dist), _ptr(nit), None, None,
+                                             _ptr(status), _capi.QT_HOST_PTR))
+        _check_shots(status)
+        return (dist, dict(nit=nit, status=status)) if return_info else dist
+
+    def mle_dist_dev(self, counts, centre, dist, init="lin", max_iter=100, tol=1e-3, rho=None, nit=None, nfev=None,
+                     fun=None, status=None):
+        self._dev_call()
+        self._chk(self.lib.qt_mle_dist_batch(self._h, _ptr(counts), counts.shape[0],
+                                             _capi.QT_INIT_LIN if init == "lin" else _capi.QT_INIT_MIXED, int(max_iter),
+                                             float(tol), _ptr(centre), _ptr(rho), _ptr(dist), _ptr(nit), _ptr(nfev),
+                                             _ptr(fun), _ptr(status), _capi.QT_DEVICE_PTR))
+
     # ---- a16 --------------------------------------------------------------------------------
     def hs_dist(self, rho, centre):
         rho = _c128(rho)
@@ -530,6 +606,70 @@ class Engine:
         self._chk(self.lib.qt_sort_f64(self._h, _ptr(srt), srt.size, _capi.QT_HOST_PTR))
         self._chk(self.lib.qt_sorted_quantiles(self._h, _ptr(srt), srt.size, _ptr(cl), cl.size, _ptr(out), _capi.QT_HOST_PTR))
         return srt, out
+
+
+    def sort_dev(self, x):
+        """`x.sort()` in place for a float64 torch CUDA tensor (qt_sort_f64; NaN last like np.sort); asynchronous."""
+        self._dev_call()
+        self._chk(self.lib.qt_sort_f64(self._h, _ptr(x), x.numel(), _capi.QT_DEVICE_PTR))
+        return x
+
+    def quantiles_of_sorted(self, srt, conf_levels):
+        """interp1d(linspace(0, 1, n), srt)(conf_levels) for an already sorted CUDA tensor -> NumPy array (synchronises)."""
+        import torch
+
+        cl = _f64(np.atleast_1d(conf_levels))
+        self._dev_call()
+        q = torch.from_numpy(cl).to(srt.device)
+        out = torch.empty(cl.size, dtype=torch.float64, device=srt.device)
+        self._chk(self.lib.qt_sorted_quantiles(self._h, _ptr(srt), srt.numel(), _ptr(q), cl.size, _ptr(out), _capi.QT_DEVICE_PTR))
+        self.sync()
+        return out.cpu().numpy()
+
+    # ---- a16 over ranks: the four local steps of the distributed selection (quantpy_amd.distributed) -------------
+    def select_splitters(self, srt, stride, n_split, out):
+        self._dev_call()
+        self._chk(self.lib.qt_select_splitters(self._h, _ptr(srt) if srt.numel() else None, srt.numel(), int(stride),
+                                               int(n_split), _ptr(out), _capi.QT_DEVICE_PTR))
+
+    def select_bracket(self, splitters, sizes, stride, n_total, levels, lo_key, hi_key):
+        """splitters (N, P) float64, sizes (N,) int64, levels (L,) float64, lo_key / hi_key (L,) int64 (bit patterns)"""
+        self._dev_call()
+        n_ranks, n_split = splitters.shape
+        self._chk(self.lib.qt_select_bracket(self._h, _ptr(splitters), n_ranks, n_split, _ptr(sizes), int(stride),
+                                             int(n_total), _ptr(levels), levels.numel(), _ptr(lo_key), _ptr(hi_key),
+                                             _capi.QT_DEVICE_PTR))
+
+    def select_window(self, srt, lo_key, hi_key, width, window):
+        self._dev_call()
+        self._chk(self.lib.qt_select_window(self._h, _ptr(srt) if srt.numel() else None, srt.numel(), _ptr(lo_key),
+                                            _ptr(hi_key), lo_key.numel(), int(width), _ptr(window), _capi.QT_DEVICE_PTR))
+
+    def select_finish(self, windows, n_total, levels, out, overflow):
+        """windows (N, L, 2 + W) float64 -> out (L,); overflow (1,) int32"""
+        self._dev_call()
+        n_ranks, n_lev, w2 = windows.shape
+        self._chk(self.lib.qt_select_finish(self._h, _ptr(windows), n_ranks, n_lev, w2 - 2, int(n_total), _ptr(levels),
+                                            _ptr(out), _ptr(overflow), _capi.QT_DEVICE_PTR))
+
+    def merge_sorted(self, runs, lengths, out=None):
+        """Merge sorted runs stored back to back (np.sort's order, NaN last).  runs: float64 torch CUDA tensor (then `out`
+        likewise, asynchronous) or NumPy array (a new array is returned); lengths: host integers."""
+        ln = np.ascontiguousarray(lengths, dtype=np.int64)
+        if _is_dev(runs):
+            import torch
+
+            self._dev_call()
+            if out is None:
+                out = torch.empty_like(runs)
+            assert int(ln.sum()) == runs.numel() == out.numel() and out.data_ptr() != runs.data_ptr()
+            self._chk(self.lib.qt_merge_sorted(self._h, _ptr(runs), _ptr(ln), ln.size, _ptr(out), _capi.QT_DEVICE_PTR))
+            return out
+        r = _f64(runs)
+        assert int(ln.sum()) == r.size
+        res = np.empty_like(r)
+        self._chk(self.lib.qt_merge_sorted(self._h, _ptr(r), _ptr(ln), ln.size, _ptr(res), _capi.QT_HOST_PTR))
+        return res
 
 
 _ENGINES = {}

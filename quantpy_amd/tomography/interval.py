@@ -176,10 +176,8 @@ class BootstrapStateInterval(ConfidenceInterval):
                 self.state = tmg.point_estimate(method=self.method, physical=self.physical, init=self.init,
                                                 tol=self.tol, max_iter=self.max_iter)
         boot = tmg.__class__(self.state, tmg.dst)
-        if (self.sampler == "device" and self.n_points and qdist.world()[1] == 1 and tmg.dst is hs_dst
-                and self.method in ("lin", "mle")):
-            self.boot_dist = self._setup_on_device(boot)
-            self._finish(self.boot_dist)
+        if self.n_points and tmg.dst is hs_dst and self.method in ("lin", "mle"):
+            self._setup_fused(boot)
             return
         # every resample's counts, one global RNG stream in the reference's order (resample after resample, setting
         # after setting): ONE call of the C restatement of NumPy's sampler instead of n_points x S Python calls
@@ -204,50 +202,88 @@ class BootstrapStateInterval(ConfidenceInterval):
         self.boot_dist = qdist.sharded_map(counts, reconstruct)
         self._finish(self.boot_dist)
 
-
-    def _setup_on_device(self, boot):
-        """sampler='device' on one GPU with the Hilbert-Schmidt distance: draws (qt_device_multinomial), reconstructions
-        and distances are enqueued back to back and stay in HBM; the distances come back.  `boot_counts` is fetched only
-        if somebody reads it."""
+    def _setup_fused(self, boot):
+        """The loop of interval.py:598-609 for the Hilbert-Schmidt distance and the 'lin' / 'mle' estimators, as this
+        rank's shard of it: the shard's counts go to (sampler='numpy': one C call on np.random's stream on rank 0,
+        broadcast) or are drawn in (sampler='device': rows keyed by their global index, each rank draws only its own)
+        HBM, ONE launch family reconstructs them and writes the distance to `state` (qt_lin_dist_batch /
+        qt_mle_dist_batch: 8 bytes per resample leave the kernel, no density matrices), the shard is sorted where it is,
+        and `cl_to_dist` evaluates interp1d's order statistics across the ranks (quantpy_amd.distributed.ShardedSample)
+        -- no all-gather of the sample unless somebody reads `boot_dist` / `cl_to_dist.y`."""
         import torch
 
+        from .. import _capi
         from ..sampling import resolve_seed
         from .state import born_probabilities
-        from .. import _capi
 
         tmg = self.tmg
+        rank, world = qdist.world()
+        lo, hi = qdist.shard_bounds(self.n_points)
         povm_matrix, shots = boot._experiment_arguments(tmg.n_measurements, tmg.povm_matrix)
-        pvals = born_probabilities(povm_matrix, self.state.bloch)
-        if not (np.all(pvals >= 0) and np.all(pvals[:, :-1].sum(1) <= 1.0 + 1e-12)):
-            raise ValueError("sum(pvals[:-1]) > 1.0")
         boot.povm_matrix, boot.n_measurements = povm_matrix, np.asarray(shots)
         eng = boot._engine()
-        n_set, n_out = pvals.shape
-        b, d = self.n_points, 2 ** self.state.n_qubits
         dev = torch.device("cuda", eng.device)
-        counts = torch.empty((b, n_set, n_out), dtype=torch.int64, device=dev)
-        eng.device_multinomial(np.asarray(shots).astype(np.int64), pvals, b * n_set, resolve_seed(self.seed), out=counts)
-        rho = torch.empty((b, d, d), dtype=torch.complex128, device=dev)
-        status = torch.zeros(b, dtype=torch.int32, device=dev)
-        if self.method == "lin":
-            eng.lin_dev(counts, rho, physical=self.physical, status=status)
+        n_set, n_out = np.asarray(povm_matrix).shape[:2]
+        d = 2 ** self.state.n_qubits
+        if self.sampler == "device":
+            pvals = born_probabilities(povm_matrix, self.state.bloch)
+            if not (np.all(pvals >= 0) and np.all(pvals[:, :-1].sum(1) <= 1.0 + 1e-12)):
+                raise ValueError("sum(pvals[:-1]) > 1.0")
+            seed = resolve_seed(self.seed)
+            if world > 1:  # one Philox key for the whole table: rank 0's
+                seed = int(qdist.broadcast_array(np.array([seed], dtype=np.uint64))[0])
+            counts = torch.empty((hi - lo, n_set, n_out), dtype=torch.int64, device=dev)
+            if hi > lo:
+                eng.device_multinomial(np.asarray(shots).astype(np.int64), pvals, (hi - lo) * n_set, seed,
+                                       first_row=lo * n_set, out=counts)
+            self._boot_counts_host, self._boot_counts_device = None, counts
+        elif self.sampler == "numpy":
+            host = boot.experiment_batch(tmg.n_measurements, tmg.povm_matrix, self.n_points) if rank == 0 or world == 1 else \
+                np.empty((self.n_points, n_set, n_out), dtype=np.int64)
+            host = qdist.broadcast_array(host)
+            self.boot_counts = host
+            counts = torch.from_numpy(np.ascontiguousarray(host[lo:hi])).to(dev)
         else:
-            eng.mle_dev(counts, rho, init=self.init, max_iter=self.max_iter, tol=self.tol, status=status)
-        dist = torch.empty(b, dtype=torch.float64, device=dev)
+            raise ValueError(f"sampler must be 'numpy' or 'device', not {self.sampler!r}")
+        dist = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+        status = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
         centre = torch.from_numpy(np.ascontiguousarray(self.state.matrix, dtype=np.complex128)).to(dev)
-        eng.hs_dist_dev(rho, centre, dist)
+        if hi > lo:
+            if self.method == "lin":
+                eng.lin_dist_dev(counts, centre, dist, physical=self.physical, status=status)
+            else:
+                eng.mle_dist_dev(counts, centre, dist, init=self.init, max_iter=self.max_iter, tol=self.tol, status=status)
         eng.sync()
         st = status.cpu().numpy()
-        if np.any(st == 1):
+        bad = np.array([int(np.any(st == 1)), int(np.any(st == _capi.TRIAL_SHOTS))])
+        if world > 1:  # every rank raises, or none
+            bad = qdist.allgather_equal(bad).max(axis=0)
+        if bad[0]:
             raise np.linalg.LinAlgError("starting point of the MLE is not positive definite")
-        if np.any(st == _capi.TRIAL_SHOTS):
+        if bad[1]:
             raise ValueError("per-setting totals of a trial do not match the registered shots")
-        self._boot_counts_device = counts
-        boot.results = counts[-1].cpu().numpy()  # the tomograph is left as the last experiment() would leave it
-        return dist.cpu().numpy()
+        if self.sampler == "device" and world == 1:
+            boot.results = counts[-1].cpu().numpy()  # the tomograph is left as the last experiment() would leave it
+        self._dist_shard = dist.clone()  # resample order (boot_dist); the sample below is sorted in place
+        self._boot_dist = None
+        self.sample = qdist.ShardedSample(dist, self.n_points, engine=eng)
+        self.cl_to_dist = _SampleInterp(self.sample)
+
+    @property
+    def boot_dist(self):
+        """The distances in resample order, on the host (all-gathered on first use when the ranks hold shards)."""
+        if getattr(self, "_boot_dist", None) is None and getattr(self, "_dist_shard", None) is not None:
+            self._boot_dist = qdist.allgather_device(self._dist_shard, self.n_points).cpu().numpy()
+        return getattr(self, "_boot_dist", None)
+
+    @boot_dist.setter
+    def boot_dist(self, value):
+        self._boot_dist, self._dist_shard = value, None
 
     @property
     def boot_counts(self):
+        """Every resample's counts on the host.  sampler='device': this rank's shard only (rows lo .. hi of the table),
+        fetched when somebody reads it."""
         if getattr(self, "_boot_counts_host", None) is None and getattr(self, "_boot_counts_device", None) is not None:
             self._boot_counts_host = self._boot_counts_device.cpu().numpy()
         return getattr(self, "_boot_counts_host", None)
@@ -255,6 +291,31 @@ class BootstrapStateInterval(ConfidenceInterval):
     @boot_counts.setter
     def boot_counts(self, value):
         self._boot_counts_host, self._boot_counts_device = value, None
+
+
+class _SampleInterp:
+    """`interp1d(np.linspace(0, 1, n), sorted_dist)` (interval.py:611-612) over a `ShardedSample`: calling it evaluates
+    the order statistics where the shards are (collective when there are several ranks); `.x` / `.y` are interp1d's
+    attributes, `.y` gathering the sorted sample on first use."""
+
+    def __init__(self, sample):
+        self.sample = sample
+
+    def __call__(self, conf_levels):
+        cl = np.asarray(conf_levels, dtype=np.float64)
+        return self.sample.quantiles(cl.reshape(-1)).reshape(cl.shape)
+
+    @property
+    def y(self):
+        full = self.sample.gather_sorted()
+        if not isinstance(full, np.ndarray):
+            self.sample.engine.sync()
+            full = full.cpu().numpy()
+        return full
+
+    @property
+    def x(self):
+        return np.linspace(0, 1, self.sample.n_total)
 
 
 class MHMCStateInterval(ConfidenceInterval):

@@ -53,6 +53,7 @@ def test_device_pointer_calls_match_host_calls(oracle):
     eng.timer_begin()
     eng.mle_dev(cd, rho_d)
     assert eng.timer_end() > 0
+    eng.follow_torch_stream()  # (the cached engine goes back to following torch's current stream)
 
 
 def test_born_probs_device_and_batch_shapes(oracle):

@@ -220,6 +220,14 @@ int qt_select_finish(qt_handle_t* h, const double* windows, int N, int L, int W,
  * order (NaN last), by ceil(log2 R) merge-path passes.  out must not alias runs. */
 int qt_merge_sorted(qt_handle_t* h, const double* runs, const int64_t* run_lengths, int R, double* out, int flags);
 
+/* ---- f2: quantpy/stats.py:21-47 over a batch of trials (MomentInterval, interval.py:59-110) ----------------------
+ * mean[b], var[b] of ||P (f_b - p)||^2 under multinomial noise, f_b[s][k] = counts[b][s][k] / ns[s] (interval.py:73,
+ * :82), n_trials = the shots per setting (interval.py:89: n_measurements[0]), weights W = P^T P with
+ * P = inv_matrix[rows][S*K] (the left inverse of the design matrix / dim, interval.py:75-87; W is formed on the matrix
+ * cores).  For process tomography S = (input states) x (settings).  S * K <= 8192. */
+int qt_moment_batch(qt_handle_t* h, const int64_t* counts, int B, int S, int K, const double* ns, const double* inv_matrix,
+                    int rows, double n_trials, double* mean, double* var, int flags);
+
 /* Metropolis-Hastings chains on the Cholesky parameters (mhmc.py:80-119 with `normalized_update`, used by
  * MHMCStateInterval, interval.py:735-750): C independent chains (the reference runs one), each on its
  * own counts[c][S][K]; x_init[C][D]; proposal increments deltas[C][T][D] and uniforms[C][T] drawn by the

@@ -979,3 +979,54 @@ def mhmc_process_interval(counts, povm_matrix, in_states, channel_choi, n_points
     samples = [vec2mat(v.real) for v in states[burn_steps::thinning][:n_points]]
     dist = np.sort([hs_dst(m, channel_choi) for m in samples])
     return dist, samples, float(np.mean(acc[burn_steps:]))
+
+
+# --------------------------------------------------------------------------------------
+# f2: moments of the squared l2 error under multinomial noise      (reference stats.py:21-47, interval.py:59-110)
+# --------------------------------------------------------------------------------------
+# The six-index contractions of stats.py, term by term (sign, subscripts over (weights, weights, freq...)): the first
+# moment's two terms (stats.py:25) and the second moment's twelve (stats.py:35-46).
+_L2_FIRST = ((+1, "aiai,ai->"), (-1, "aiaj,ai,aj->"))
+_L2_SECOND = ((+1, "aiaj,bkbl,ai,aj,bk,bl->"), (-1, "aiaj,bkbk,ai,aj,bk->"), (-1, "aiai,bkbl,ai,bk,bl->"), (+1, "aiai,bkbk,ai,bk->"),
+              (+1, "aibj,bkal,ai,bj,bk,al->"), (-1, "aibj,bjal,ai,bj,al->"), (-1, "aibj,bkai,ai,bj,bk->"), (+1, "aibj,bjai,ai,bj->"),
+              (+1, "aibj,akbl,ai,bj,ak,bl->"), (-1, "aibj,akbj,ai,bj,ak->"), (-1, "aibj,aibl,ai,bj,bl->"), (+1, "aibj,aibj,ai,bj->"))
+
+
+def _l2_terms(terms, freq, weights):
+    total = 0.0
+    for sign, subs in terms:
+        n_w = 1 if len(subs.split("->")[0].split(",")[1]) == 2 else 2  # one or two weight tensors lead the operand list
+        n_f = len(subs.split("->")[0].split(",")) - n_w
+        total += sign * np.einsum(subs, *([weights] * n_w + [freq] * n_f), optimize=True)
+    return total
+
+
+def l2_moments(freq, n_trials, inv_matrix):
+    """(mean, variance) of ||P (f - p)||^2 for multinomial frequencies `freq` (S, K), `n_trials` shots per setting and
+    P = `inv_matrix` (rows, S*K): stats.py:5-47 (l2_mean, l2_variance) with the weights tensor of interval.py:88,
+    einsum('aij,akl->ijkl', P, P)."""
+    s, k = freq.shape
+    p3 = np.asarray(inv_matrix).reshape(-1, s, k)
+    weights = np.einsum("aij,akl->ijkl", p3, p3)
+    first = _l2_terms(_L2_FIRST, freq, weights) / n_trials
+    second = _l2_terms(_L2_SECOND, freq, weights) / n_trials**2
+    return first, second - first**2
+
+
+def moment_radii(counts, povm_matrix, conf_levels, distr_type="gamma"):
+    """MomentInterval for state tomography with the Hilbert-Schmidt distance (interval.py:72-76, 88-110)."""
+    import scipy.stats as sts
+
+    counts = np.asarray(counts)
+    n_meas = counts.sum(-1).astype(float)
+    dim = int(round(math.sqrt(povm_matrix.shape[-1])))
+    inv = left_inv(povm_matrix.reshape(-1, povm_matrix.shape[-1])) / dim
+    mean, var = l2_moments(counts / n_meas[:, None], n_meas[0], inv)
+    if distr_type == "gamma":
+        scale = var / mean
+        distr = sts.gamma(a=mean / scale, scale=scale)
+    elif distr_type == "norm":
+        distr = sts.norm(loc=mean, scale=np.sqrt(var))
+    else:
+        distr = sts.expon(scale=mean)
+    return np.sqrt(distr.ppf(conf_levels)) * np.sqrt(dim / 2)

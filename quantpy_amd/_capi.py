@@ -63,6 +63,7 @@ SIGNATURES = {
     "qt_select_window": (_c_int, [_vp, _vp, ctypes.c_longlong, _vp, _vp, _c_int, _c_int, _vp, _c_int]),
     "qt_select_finish": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp, _vp, _vp, _c_int]),
     "qt_merge_sorted": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int]),
+    "qt_moment_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _c_int]),
     "qt_legacy_multinomial": (_c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp]),
     "qt_device_multinomial": (_c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_longlong, _c_int, _vp, _vp, _c_int, _vp,
                                        _c_int]),

@@ -124,8 +124,9 @@ struct Large {
       L[c.e] = dl;
       __syncthreads();
       const cd dt = L[c.j * LD + c.i];
-      const double sr = bsum(c, dl.re * dt.re - dl.im * dt.im);
-      const double si = bsum(c, dl.re * dt.im + dl.im * dt.re);
+      const cd tm = hs_term(dl, dt);
+      const double sr = bsum(c, tm.re);
+      const double si = bsum(c, tm.im);
       const double v = sqrt(hypot(sr, si)) / sqrt(2.0);
       if (c.t == 0) o.dist[b] = v < 1e-15 ? 0.0 : v;
     }

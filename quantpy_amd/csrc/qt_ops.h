@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "qt_small.h"  // gsum / dpp reductions
+
 namespace qt {
 
 // ---- a1: routines.py:14-19 ----------------------------------------------------------------
@@ -550,15 +552,16 @@ __global__ void __launch_bounds__(64) k_hs_dist(int d, const double* __restrict_
   for (int e = threadIdx.x; e < d * d; e += 64) {
     const int i = e / d, j = e % d;
     const int et = j * d + i;
-    const double ar = r[2 * e] - centre[2 * e], ai = r[2 * e + 1] - centre[2 * e + 1];
-    const double br = r[2 * et] - centre[2 * et], bi = r[2 * et + 1] - centre[2 * et + 1];
-    sr += ar * br - ai * bi;  // (Delta Delta)_ii summed = sum_ij Delta_ij Delta_ji
-    si += ar * bi + ai * br;
+    const cd dl{r[2 * e] - centre[2 * e], r[2 * e + 1] - centre[2 * e + 1]};
+    const cd dt{r[2 * et] - centre[2 * et], r[2 * et + 1] - centre[2 * et + 1]};
+    const cd t = hs_term(dl, dt);  // (Delta Delta)_ii summed = sum_ij Delta_ij Delta_ji
+    sr += t.re;
+    si += t.im;
   }
-  for (int m = 32; m >= 1; m >>= 1) {
-    sr += __shfl_xor(sr, m, 64);
-    si += __shfl_xor(si, m, 64);
-  }
+  // the reduction tree of the estimators' fused distance (Small::hs_to_centre): for d <= 8 -- one element per lane --
+  // the two-pass and the one-pass distance are the same bits
+  sr = gsum<64>(sr);
+  si = gsum<64>(si);
   if (threadIdx.x == 0) {
     const double v = sqrt(hypot(sr, si)) / sqrt(2.0);
     dist[b] = v < 1e-15 ? 0.0 : v;
@@ -620,8 +623,14 @@ __device__ __forceinline__ InterpCell interp_cell(long long n, double x) {
   if (hi < 1) hi = 1;
   return InterpCell{hi - 1, grid(hi - 1), grid(hi)};
 }
+// scipy's expression, operation by operation: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x - x_lo) + y_lo.
+// No contraction: an fma in place of the last multiply-add changes the last bit (seen at n = 3, where x - x_lo is not a
+// power of two times the slope's scale), and the bootstrap quantiles are compared with interp1d bit for bit.
 __device__ __forceinline__ double interp_value(const InterpCell& c, double x, double yl, double yh) {
-  return (yh - yl) / (c.xh - c.xl) * (x - c.xl) + yl;
+#pragma clang fp contract(off)
+  const double slope = (yh - yl) / (c.xh - c.xl);
+  const double prod = slope * (x - c.xl);
+  return prod + yl;
 }
 
 __global__ void k_interp_sorted(const double* __restrict__ y, long long n, const double* __restrict__ q, int nq,
@@ -799,6 +808,116 @@ __global__ void __launch_bounds__(1024) k_select_finish(const double* __restrict
   }
   __syncthreads();
   if (threadIdx.x == 0) out[l] = n_total == 1 ? picked[0] : interp_value(cell, x, picked[0], picked[1]);
+}
+
+// ---- f2: stats.py:21-47 l2_first_moment / l2_second_moment over a batch of trials (MomentInterval, interval.py:59-110) --
+// Mean and variance of ||P (f - p)||^2 for multinomial frequencies f[S][K] (N shots per setting) with the weights
+// W[(a,i),(b,j)] = sum_d P[d][(a,i)] P[d][(b,j)] (interval.py:88: einsum('aij,akl->ijkl')).  With
+//   U[a][(b,j)] = sum_i f_ai W[(a,i),(b,j)],  Q_ab = sum_j U[a][(b,j)] f_bj,  t = sum_ai W[(a,i),(a,i)] f_ai
+// the reference's fourteen einsums collect to (W symmetric)
+//   E  = (t - tr Q) / N
+//   E2 = ((tr Q - t)^2 + 2 sum_ab Q_ab^2 - 4 sum_a sum_bj U[a][(b,j)]^2 f_bj + 2 f^T (W o W) f) / N^2,   Var = E2 - E^2.
+// One workgroup takes T trials and walks the settings a: thread c owns columns c, c + 256, ... of W (so a wavefront reads
+// 512 contiguous bytes of each row, and every row once per workgroup: W is read B / T times from L2 in all), keeps
+// U[a][c] for its columns in registers while the K rows of setting a go by, squares / multiplies on the spot, and leaves
+// U[a][c] f_c in LDS for the segmented sums Q_ab (K consecutive columns) that threads b < S square and add up.
+template <int T, int NC>
+__global__ void __launch_bounds__(256) k_moment_batch(const int64_t* __restrict__ counts, int B, int S, int K,
+                                                      const double* __restrict__ ns, const double* __restrict__ W,
+                                                      double n_trials, double* __restrict__ mean,
+                                                      double* __restrict__ var) {
+  extern __shared__ double sm[];
+  const int M = S * K, tid = threadIdx.x;
+  double* f = sm;               // [T][M]
+  double* prod = sm + T * M;    // [T][M]
+  __shared__ double red[4][5 * T];
+  const int b0 = blockIdx.x * T;
+  for (int e = tid; e < T * M; e += 256) {
+    const int t = e / M, r = e % M, b = b0 + t;
+    f[e] = b < B ? (double)counts[(size_t)b * M + r] / ns[r / K] : 0.0;
+  }
+  __syncthreads();
+  double uuf[T], wwf[T], tdiag[T], q2[T], trq[T], ww[NC][T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) uuf[t] = wwf[t] = tdiag[t] = q2[t] = trq[t] = 0.0;
+#pragma unroll
+  for (int n = 0; n < NC; ++n)
+#pragma unroll
+    for (int t = 0; t < T; ++t) ww[n][t] = 0.0;
+  for (int a = 0; a < S; ++a) {
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = tid + 256 * n;
+      if (c < M) {
+        double u[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) u[t] = 0.0;
+        for (int i = 0; i < K; ++i) {
+          const int r = a * K + i;
+          const double w = W[(size_t)r * M + c], w2 = w * w;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const double fr = f[t * M + r];
+            u[t] = fma(fr, w, u[t]);
+            ww[n][t] = fma(fr, w2, ww[n][t]);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const double fc = f[t * M + c], uf = u[t] * fc;
+          uuf[t] = fma(u[t], uf, uuf[t]);
+          prod[t * M + c] = uf;
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < T * S; e += 256) {  // Q_ab for every b of every trial
+      const int t = e / S, b = e % S;
+      const double* p = prod + t * M + b * K;
+      double q = 0.0;
+      for (int j = 0; j < K; ++j) q += p[j];
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt)
+        if (tt == t) {
+          q2[tt] = fma(q, q, q2[tt]);
+          if (b == a) trq[tt] += q;
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int c = tid + 256 * n;
+    if (c < M) {
+      const double wd = W[(size_t)c * M + c];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const double fc = f[t * M + c];
+        wwf[t] = fma(ww[n][t], fc, wwf[t]);
+        tdiag[t] = fma(wd, fc, tdiag[t]);
+      }
+    }
+  }
+  // five sums per trial over the workgroup
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    double v[5] = {uuf[t], wwf[t], tdiag[t], q2[t], trq[t]};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      v[k] = gsum<64>(v[k]);
+      if ((tid & 63) == 0) red[tid >> 6][5 * t + k] = v[k];
+    }
+  }
+  __syncthreads();
+  if (tid < T && b0 + tid < B) {
+    double v[5];
+    for (int k = 0; k < 5; ++k) v[k] = (red[0][5 * tid + k] + red[1][5 * tid + k]) + (red[2][5 * tid + k] + red[3][5 * tid + k]);
+    const double s_uuf = v[0], s_wwf = v[1], t_d = v[2], s_q2 = v[3], tr_q = v[4];
+    const double first = (t_d - tr_q) / n_trials;
+    const double second = ((tr_q - t_d) * (tr_q - t_d) + 2.0 * s_q2 - 4.0 * s_uuf + 2.0 * s_wwf) / (n_trials * n_trials);
+    mean[b0 + tid] = first;
+    var[b0 + tid] = second - first * first;
+  }
 }
 
 // ---- merge of two adjacent sorted runs (gather of sorted shards -> the sorted sample; np.sort's order, NaN last) ------

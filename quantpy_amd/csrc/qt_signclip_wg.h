@@ -91,8 +91,8 @@ struct SignClipWG {
     double* red = sm + o.red;
     // (images are picked by OFFSET from the LDS base: an array of pointers indexed at run time makes the compiler
     //  lose the address space and emit flat_* for every access in the loop -- DESIGN.md section 4.5)
-    int xo = o.img0, yo = o.img1;
-    const int wo = o.img2;
+    int xo = o.img0, wo = o.img2;
+    const int yo = o.img1;
     if (i == j) a.im = 0.0;
     const double nrm2 = wsum(red, a.re * a.re + a.im * a.im);
     if (!(nrm2 > 0.0)) {  // the zero matrix (or NaN input): every eigenvalue is clipped to eps
@@ -105,24 +105,83 @@ struct SignClipWG {
     __syncthreads();
     bool lifting = true;
     int ns_left = 12;
-    for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (wsum returns identical bits)
-      cd* X = reinterpret_cast<cd*>(sm + xo);
+    // Round 3: a step is TWO barrier-separated phases on the wavefronts that own the product tiles (it was five, with
+    // every thread of the workgroup reading Y, reducing res and writing W in between): the residual comes out of the
+    // accumulators of Y = X^2, and X (alpha I + beta Y) = alpha X + beta X Y is finished in the accumulators of the
+    // second product, whose B operand is the Hermitian part of Y taken on the fly.  At d = 32 a step was ~5 k clocks of
+    // mostly barrier and LDS round-trip latency, ~25 steps per clipped trial (130 k of its 319 k clocks).
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool mm = wave < 2 * NTILE;  // wave-uniform
+    const int tile = wave >> 1, part = wave & 1;
+    const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
+    const int r16 = lane & 15, kq = lane >> 4;
+    for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (identical bits in every thread)
+      const cd* X = reinterpret_cast<const cd*>(sm + xo);
       cd* Y = reinterpret_cast<cd*>(sm + yo);
-      cd* W = reinterpret_cast<cd*>(sm + wo);
-      matmul(X, X, Y);
-      const cd y0 = Y[e], yt = Y[et];
-      const cd y{0.5 * (y0.re + yt.re), 0.5 * (y0.im - yt.im)};  // Hermitian part
-      const double dr = dlt - y.re;
-      const double res = wsum(red, dr * dr + y.im * y.im);
+      cd* Xn = reinterpret_cast<cd*>(sm + wo);
+      if (mm) {  // phase 1: Y = X X, and this tile's share of res = ||I - Y||_F^2
+        sc_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        const cd* ap = X + (row0 + r16) * P + kq;
+        const cd* bp = X + kq * P + col0 + r16;
+#pragma unroll
+        for (int k0 = 0; k0 < d; k0 += 4) {
+          const cd av = ap[k0], bv = bp[k0 * P];
+          if (part == 0) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.re, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.im, bv.im, acc, 0, 0, 0);
+          } else {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.im, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.re, acc, 0, 0, 0);
+          }
+        }
+        double* ydst = reinterpret_cast<double*>(Y) + part;
+        double rp = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + kq + 4 * r, col = col0 + r16;
+          ydst[(row * P + col) * 2] = acc[r];
+          const double dv = (part == 0 && row == col) ? 1.0 - acc[r] : acc[r];
+          rp = fma(dv, dv, rp);
+        }
+        rp = gsum<64>(rp);
+        if (lane == 0) red[wave] = rp;
+      }
+      __syncthreads();
+      double res = 0.0;
+#pragma unroll
+      for (int w = 0; w < 2 * NTILE; ++w) res += red[w];
       if (lifting && (res < 0.5 || k >= 40)) lifting = false;
       const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);  // one more quadratic step squares the error
       const double alpha = lifting ? 2.0 : 1.5, beta = lifting ? -1.0 : -0.5;
-      W[e] = cd{fma(beta, y.re, alpha * dlt), beta * y.im};
+      if (mm) {  // phase 2: X_next = alpha X + beta X Yh, Yh = (Y + Y^dagger) / 2 read on the fly
+        sc_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        const cd* ap = X + (row0 + r16) * P + kq;
+        const cd* bp = Y + kq * P + col0 + r16;       // Y[k][col]
+        const cd* bt = Y + (col0 + r16) * P + kq;     // Y[col][k]
+#pragma unroll
+        for (int k0 = 0; k0 < d; k0 += 4) {
+          const cd av = ap[k0], b0 = bp[k0 * P], b1 = bt[k0];
+          const double br = 0.5 * (b0.re + b1.re), bi = 0.5 * (b0.im - b1.im);
+          if (part == 0) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, br, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.im, bi, acc, 0, 0, 0);
+          } else {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, br, acc, 0, 0, 0);
+          }
+        }
+        const double* xsrc = reinterpret_cast<const double*>(X) + part;
+        double* xdst = reinterpret_cast<double*>(Xn) + part;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int at = ((row0 + kq + 4 * r) * P + col0 + r16) * 2;
+          xdst[at] = fma(beta, acc[r], alpha * xsrc[at]);
+        }
+      }
       __syncthreads();
-      matmul(X, W, Y);  // X_next lands in Y
-      const int tmp = xo;
-      xo = yo;
-      yo = tmp;
+      const int tmp = xo;  // the new X sits in the third image; the old X image is the next step's target
+      xo = wo;
+      wo = tmp;
       if (last || !(res == res)) break;
     }
     // S = sign(A) sits in the image at xo.  R = (A + A S) / 2 + eps (I - S) / 2

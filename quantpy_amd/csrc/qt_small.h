@@ -63,6 +63,11 @@ __device__ __forceinline__ cd cmulc(cd a, cd b) {  // a * conj(b)
   return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im};
 }
 __device__ __forceinline__ cd cadd(cd a, cd b) { return {a.re + b.re, a.im + b.im}; }
+// One term Delta_ij Delta_ji of Tr(Delta^2) (geometry.py:16), with its rounding pinned (one product rounded, then one
+// fma) so that every kernel that forms a Hilbert-Schmidt distance gets the same bits from the same operands.
+__device__ __forceinline__ cd hs_term(cd a, cd b) {
+  return {__builtin_fma(a.re, b.re, -(a.im * b.im)), __builtin_fma(a.re, b.im, a.im * b.re)};
+}
 __device__ __forceinline__ cd cscale(cd a, double s) { return {a.re * s, a.im * s}; }
 
 // LDS hand-off inside ONE wavefront: order this wave's LDS writes before its later reads.  The hardware already does:
@@ -1276,8 +1281,9 @@ struct Small {
     const cd dl{r.re - cc.x, r.im - cc.y};
     const int src = (int)(threadIdx.x & 63) - c.l + c.j * d + c.i;
     const cd dt{__shfl(dl.re, src, 64), __shfl(dl.im, src, 64)};
-    const double sr = gsum<G>(dl.re * dt.re - dl.im * dt.im);
-    const double si = gsum<G>(dl.re * dt.im + dl.im * dt.re);
+    const cd t = hs_term(dl, dt);
+    const double sr = gsum<G>(t.re);
+    const double si = gsum<G>(t.im);
     const double v = sqrt(hypot(sr, si)) / sqrt(2.0);
     return v < 1e-15 ? 0.0 : v;
   }
@@ -1397,8 +1403,11 @@ __global__ void __launch_bounds__(256) k_nll_batch(PovmView pv, const double* __
 // high-shot trial, where BFGS exits at iteration 0 -- are finished here; the
 // rest hand x0, g0, f0 to k_mle_bfgs.  Keeping the D x D inverse Hessian out of this kernel
 // keeps its register footprint small.
+// Held to four wavefronts per SIMD (128 VGPRs): the saturated batches run four workgroups per CU, and one
+// register more -- the EstOut pointers of round 3 made it 129 -- takes a workgroup off every CU (measured: 0.372 -> 0.416 ms
+// per 65 536 trials).
 template <int NQ, bool ALDS>
-__global__ void __launch_bounds__(256) k_mle_start(PovmView pv, const int64_t* __restrict__ counts, int B, int init,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_mle_start(PovmView pv, const int64_t* __restrict__ counts, int B, int init,
                                                    int max_iter, double gtol, EstOut rho,
                                                    int32_t* __restrict__ nit_out, int32_t* __restrict__ nfev_out,
                                                    double* __restrict__ fun_out, int32_t* __restrict__ status_out,

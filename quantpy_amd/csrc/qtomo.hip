@@ -1380,6 +1380,44 @@ int qt_merge_sorted(qt_handle_t* h, const double* runs, const int64_t* run_lengt
   return finish(h, flags);
 }
 
+// ---- f2: stats.py:21-47 over a batch (MomentInterval, interval.py:59-110) ------------------------------------------------
+int qt_moment_batch(qt_handle_t* h, const int64_t* counts, int B, int S, int K, const double* ns, const double* inv_matrix,
+                    int rows, double n_trials, double* mean, double* var, int flags) {
+  QT_ENTER(h);
+  if (B < 0 || S < 1 || K < 1 || rows < 1 || !(n_trials > 0.0) || !ns || !inv_matrix || (B > 0 && (!counts || !mean || !var)))
+    return fail(QT_ERR_ARG, "bad moment_batch arguments");
+  const long long M = (long long)S * K;
+  if (M > 8192) return fail(QT_ERR_UNSUPPORTED, "qt_moment_batch supports up to 8192 POVM rows (got %lld)", M);
+  if (B == 0) return 0;
+  const int64_t* dc;
+  const double *dns, *dp;
+  double *dmean, *dvar;
+  if (int r = stage_in(h, h->in0, counts, (size_t)B * M, flags, &dc)) return r;
+  if (int r = stage_in(h, h->in1, ns, (size_t)S, flags, &dns)) return r;
+  if (int r = stage_in(h, h->out2, inv_matrix, (size_t)rows * M, flags, &dp)) return r;
+  if (int r = stage_out(h, h->out0, mean, (size_t)B, flags, &dmean)) return r;
+  if (int r = stage_out(h, h->out1, var, (size_t)B, flags, &dvar)) return r;
+  // W = P^T P on the matrix cores ([M x rows] . [rows x M])
+  HIPCHK(h->out3.ensure((size_t)M * M * sizeof(double)));
+  double* dW = h->out3.as<double>();
+  hipLaunchKernelGGL(qt::k_gemm<0>, dim3((unsigned)((M + 15) / 16), (unsigned)((M + 15) / 16)), dim3(64), 0, h->stream, (int)M, (int)M,
+                     rows, dp, (int)M, 1, dp, (int)M, 0, dW, (int)M);
+  if (M <= 1024) {
+    constexpr int T = 4;
+    const size_t lds = (size_t)2 * T * M * sizeof(double);
+    if (int r = allow_big_lds(qt::k_moment_batch<T, 4>, lds)) return r;
+    hipLaunchKernelGGL((qt::k_moment_batch<T, 4>), dim3((B + T - 1) / T), dim3(256), lds, h->stream, dc, B, S, K, dns, dW, n_trials,
+                       dmean, dvar);
+  } else {
+    const size_t lds = (size_t)2 * M * sizeof(double);
+    if (int r = allow_big_lds(qt::k_moment_batch<1, 32>, lds)) return r;
+    hipLaunchKernelGGL((qt::k_moment_batch<1, 32>), dim3(B), dim3(256), lds, h->stream, dc, B, S, K, dns, dW, n_trials, dmean, dvar);
+  }
+  if (int r = fetch_out(h, dmean, mean, (size_t)B, flags)) return r;
+  if (int r = fetch_out(h, dvar, var, (size_t)B, flags)) return r;
+  return finish(h, flags);
+}
+
 // ---- a4 / a12 / a16 host side: state.py:109-114, the draws of experiment() (qt_sampler.h) ---------
 static int check_pvals(int period, int K, const int64_t* n, const double* pvals);
 

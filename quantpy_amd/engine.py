@@ -608,6 +608,25 @@ class Engine:
         return srt, out
 
 
+    # ---- f2: stats.py:21-47 ------------------------------------------------------------------------
+    def moments(self, counts, n_meas, inv_matrix):
+        """Mean and variance of the squared weighted l2 error of the frequencies under multinomial noise
+        (qt_moment_batch; reference stats.py l2_mean / l2_variance with the weights of interval.py:88).
+        counts (B, S, K) or (S, K); n_meas (S,) shots per setting; inv_matrix (rows, S*K) = left inverse of the design
+        matrix / dim.  -> (mean, var), each (B,) or scalars."""
+        c = _i64(counts)
+        single = c.ndim == 2
+        if single:
+            c = c[None]
+        b, s, k = c.shape
+        ns = _f64(np.broadcast_to(np.asarray(n_meas, dtype=np.float64), (s,)))
+        p = _f64(np.asarray(inv_matrix).reshape(np.asarray(inv_matrix).shape[0], -1))
+        assert p.shape[1] == s * k
+        mean, var = np.empty(b), np.empty(b)
+        self._chk(self.lib.qt_moment_batch(self._h, _ptr(c), b, s, k, _ptr(ns), _ptr(p), p.shape[0], float(ns[0]), _ptr(mean),
+                                           _ptr(var), _capi.QT_HOST_PTR))
+        return (mean[0], var[0]) if single else (mean, var)
+
     def sort_dev(self, x):
         """`x.sort()` in place for a float64 torch CUDA tensor (qt_sort_f64; NaN last like np.sort); asynchronous."""
         self._dev_call()

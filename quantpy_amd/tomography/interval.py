@@ -9,8 +9,8 @@ process group when there is one, and the distances are all-gathered (quantpy_amd
 reference's CLI scripts use: the first two moments of the squared Hilbert-Schmidt error of the
 linear-inversion estimate under multinomial noise, matched to a gamma / normal / exponential
 law.  Its one heavy step, the left inverse of the (state or process) design matrix, runs on the GPU
-(qt_left_inverse); the moment sums are O(M^2) host arithmetic, written in matrix form instead of the
-reference's six-operand einsums.
+(qt_left_inverse), and so do the moment sums (qt_moment_batch: the reference's six-operand einsums collected into
+O(M^2) matrix form, batched over trials).
 
 `MHMCStateInterval` / `MHMCProcessInterval` run their chains on the GPU (qt_mhmc_state / qt_mhmc_process);
 `SugiyamaInterval` and `HolderInterval` are closed-form / compositions over those.  The four intervals that
@@ -89,72 +89,78 @@ class ConfidenceInterval(ABC):
         self.cl_to_dist = interp1d(np.linspace(0, 1, len(dist)), dist)
 
 
-def l2_moments(freq, n_trials, inv_matrix):
-    """Mean and variance of ||W^(1/2)(f - p)||^2 for multinomial frequencies `freq` (S, K) with
-    `n_trials` shots per setting and W = P^T P, P = `inv_matrix` reshaped (D, S*K)
-    (reference stats.py:5-47: l2_mean / l2_variance with weights einsum('aij,akl->ijkl', P, P)).
-    With Q_ab = f_a^T W_ab f_b, t_a = sum_i W_aa[i,i] f_ai and U[a, (b,j)] = sum_i f_ai W[(a,i),(b,j)]:
-        E   = (sum t - tr Q) / N
-        E_2 = ((tr Q - sum t)^2 + 2 sum_ab Q_ab^2 - 4 sum_a sum_bj U[a,bj]^2 f_bj + 2 f^T (W o W) f) / N^2
-    which is the reference's twelve einsum terms collected."""
-    s, k = freq.shape
-    p = inv_matrix.reshape(inv_matrix.shape[0], s * k)
-    w = p.T @ p  # (M, M), symmetric
-    f = freq.reshape(-1)
-    w4 = w.reshape(s, k, s, k)
-    u = np.einsum("ai,aibj->abj", freq, w4)  # U[a, b, j]
-    q = np.einsum("abj,bj->ab", u, freq)
-    t = np.einsum("aiai,ai->", w4, freq)
-    tr_q = np.trace(q)
-    first = (t - tr_q) / n_trials
-    second = ((tr_q - t) ** 2 + 2 * np.sum(q * q) - 4 * np.einsum("abj,abj,bj->", u, u, freq)
-              + 2 * f @ (w * w) @ f) / n_trials**2
-    return first, second - first**2
-
-
 class MomentInterval(ConfidenceInterval):
     """Closed-form interval from the first two moments of the squared HS error of linear inversion.
-    distr_type : 'gamma' (default) | 'norm' | 'exp'."""
+    distr_type : 'gamma' (default) | 'norm' | 'exp'.
+
+    Both heavy steps run on the GPU: the left inverse of the design matrix (qt_left_inverse: MFMA Gram, pivoted
+    Gauss-Jordan) and the moment sums of stats.py:21-47 (qt_moment_batch).  `radii_batch` evaluates the interval for
+    a whole batch of count tensors of the same experiment in one launch -- the coverage study of
+    notebooks/Verification.ipynb (10 000 trials per state) is that call."""
 
     def __init__(self, tmg, distr_type="gamma"):
         super().__init__(tmg, **_pop_hidden_keys(locals()))
 
-    def setup(self):
+    def _design(self):
+        """(dim, n_measurements (S,), counts (S, K), inv_matrix (rows, S*K)) as interval.py:72-87 builds them."""
         tmg = self.tmg
         if self.mode == Mode.STATE:
             dim = 2**tmg.state.n_qubits
             n_measurements = tmg.n_measurements
-            frequencies = tmg.results / tmg.n_measurements[:, None]
+            counts = np.asarray(tmg.results)
             povm = np.asarray(tmg.povm_matrix)
             design = povm.reshape(-1, povm.shape[-1])
         else:
             dim = 4**tmg.channel.n_qubits
             first = tmg.tomographs[0]
-            n_measurements = first.n_measurements
-            frequencies = np.vstack([t.results / n_measurements[:, None] for t in tmg.tomographs])
+            n_measurements = np.tile(first.n_measurements, len(tmg.tomographs))
+            counts = np.vstack([t.results for t in tmg.tomographs])
             povm = np.asarray(first.povm_matrix)
             povm_rows = povm.reshape(-1, povm.shape[-1])
             states = np.asarray([rho.T.bloch for rho in tmg.input_basis.elements])
             design = np.einsum("sd,pi->spdi", states, povm_rows).reshape(states.shape[0] * povm_rows.shape[0], -1)
-        inv_matrix = _left_inv(design) / dim  # GPU: Gram GEMM (MFMA), pivoted Gauss-Jordan, GEMM
-        mean, variance = l2_moments(frequencies, n_measurements[0], np.asarray(inv_matrix))
+        inv_matrix = np.asarray(_left_inv(design)) / dim  # GPU: Gram GEMM (MFMA), pivoted Gauss-Jordan, GEMM
+        return dim, np.asarray(n_measurements, dtype=np.float64), counts, inv_matrix
+
+    def _engine(self):
+        tmg = self.tmg
+        return get_engine(tmg.state.n_qubits if self.mode == Mode.STATE else tmg.channel.n_qubits)
+
+    def _distribution(self, mean, variance):
         if self.distr_type == "norm":
-            distr = sts.norm(loc=mean, scale=np.sqrt(variance))
-        elif self.distr_type == "gamma":
+            return sts.norm(loc=mean, scale=np.sqrt(variance))
+        if self.distr_type == "gamma":
             scale = variance / mean
-            distr = sts.gamma(a=mean / scale, scale=scale)
-        elif self.distr_type == "exp":
-            distr = sts.expon(scale=mean)
-        else:
-            raise NotImplementedError(f"Unsupported distribution type {self.distr_type}")
-        if tmg.dst == hs_dst:
-            alpha = np.sqrt(dim / 2)
-        elif tmg.dst == trace_dst:
-            alpha = dim / 2
-        else:
-            raise NotImplementedError()
+            return sts.gamma(a=mean / scale, scale=scale)
+        if self.distr_type == "exp":
+            return sts.expon(scale=mean)
+        raise NotImplementedError(f"Unsupported distribution type {self.distr_type}")
+
+    def _alpha(self, dim):
+        if self.tmg.dst == hs_dst:
+            return np.sqrt(dim / 2)
+        if self.tmg.dst == trace_dst:
+            return dim / 2
+        raise NotImplementedError()
+
+    def setup(self):
+        dim, n_measurements, counts, inv_matrix = self._design()
+        mean, variance = self._engine().moments(counts, n_measurements, inv_matrix)
+        distr = self._distribution(mean, variance)
+        alpha = self._alpha(dim)
         self.mean, self.variance = mean, variance
         self.cl_to_dist = lambda cl: np.sqrt(distr.ppf(cl)) * alpha
+
+    def radii_batch(self, counts, conf_levels):
+        """The interval's radii for B count tensors of this tomograph's experiment (same POVM, same shots): counts
+        (B, S, K) for a state, (B, 4^n, S, K) for a process -> radii (B, len(conf_levels)).  One moment launch for the
+        batch; the gamma / normal quantiles are SciPy's, vectorised over the batch."""
+        dim, n_measurements, own, inv_matrix = self._design()
+        c = np.asarray(counts)
+        c = c.reshape((c.shape[0],) + own.shape)
+        mean, variance = self._engine().moments(c, n_measurements, inv_matrix)
+        distr = self._distribution(mean[:, None], variance[:, None])
+        return np.sqrt(distr.ppf(np.asarray(conf_levels, dtype=np.float64)[None, :])) * self._alpha(dim)
 
 
 class BootstrapStateInterval(ConfidenceInterval):
@@ -231,7 +237,7 @@ class BootstrapStateInterval(ConfidenceInterval):
                 raise ValueError("sum(pvals[:-1]) > 1.0")
             seed = resolve_seed(self.seed)
             if world > 1:  # one Philox key for the whole table: rank 0's
-                seed = int(qdist.broadcast_array(np.array([seed], dtype=np.uint64))[0])
+                seed = int(qdist.broadcast_array(np.array([seed], dtype=np.uint64).view(np.int64)).view(np.uint64)[0])
             counts = torch.empty((hi - lo, n_set, n_out), dtype=torch.int64, device=dev)
             if hi > lo:
                 eng.device_multinomial(np.asarray(shots).astype(np.int64), pvals, (hi - lo) * n_set, seed,

@@ -277,25 +277,16 @@ def test_povm_tensor_guard_sees_permutations(qp, oracle):
     assert PovmTensor(full.copy(), table)[1:].valid_factor() is None  # derived arrays carry no factor
 
 
-def test_moment_sums_host_math_against_reference_radii(oracle):
-    """l2_moments (the reference's twelve stats.py einsums collected into matrix form) with the
-    oracle's CPU left inverse must reproduce the reference's MomentInterval radii."""
-    import scipy.stats as sts
-
-    from quantpy_amd.tomography.interval import l2_moments
-
+def test_oracle_moment_sums_against_reference_radii(oracle):
+    """The oracle's restatement of stats.py:21-47 (the reference's einsums term by term) with its CPU left inverse must
+    reproduce the reference's MomentInterval radii (tests/golden/moment.npz, written by the reference itself); the GPU
+    kernel qt_moment_batch is checked against both in tests/test_gpu_moments.py."""
     g = load_golden("moment")
     for k in range(int(g["n_state_cases"])):
         key = f"S{k}"
         n = int(g[key + "_n"])
-        dim = 2**n
         a = oracle.measurement_matrix(str(g[key + "_povm"]), n)
-        counts = g[key + "_counts"]
-        n_meas = counts.sum(-1)
-        inv = oracle.left_inv(a.reshape(-1, a.shape[-1])) / dim
-        mean, var = l2_moments(counts / n_meas[:, None], n_meas[0], inv)
-        scale = var / mean
-        radii = np.sqrt(sts.gamma(a=mean / scale, scale=scale).ppf(g["conf_levels"])) * np.sqrt(dim / 2)
+        radii = oracle.moment_radii(g[key + "_counts"], a, g["conf_levels"])
         assert np.allclose(radii, g[key + "_gamma"], rtol=1e-9), key
 
 

@@ -43,6 +43,18 @@ struct SignClipWG {
     int img0, img1, img2, red;
   };
 
+  // Independent accumulator chains per product tile.  A dependent v_mfma_f64_16x16x4_f64 costs ~170 clocks of latency
+  // against ~16 of issue (profiles/round3_ubench_mfma_f64_warm.txt: one chain per wavefront runs the matrix pipe at 27 of
+  // its 46 TFLOP/s), and since round 3 a step of the iteration IS two such chains plus two barriers: the d / 4 k-steps of
+  // a tile are dealt round-robin to NACC accumulators and summed at the end.  Registers: 8 per chain.
+  static constexpr int NACC = d >= 32 ? 4 : 2;
+  __device__ __forceinline__ static sc_v4f64 sum_chains(const sc_v4f64 (&a)[NACC]) {
+    sc_v4f64 s = a[0];
+#pragma unroll
+    for (int q = 1; q < NACC; ++q) s += a[q];
+    return s;
+  }
+
   __device__ static double wsum(double* red, double v) {  // identical bits in every thread
     v = gsum<64>(v);
     __syncthreads();
@@ -120,12 +132,15 @@ struct SignClipWG {
       cd* Y = reinterpret_cast<cd*>(sm + yo);
       cd* Xn = reinterpret_cast<cd*>(sm + wo);
       if (mm) {  // phase 1: Y = X X, and this tile's share of res = ||I - Y||_F^2
-        sc_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        sc_v4f64 accs[NACC];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) accs[q] = sc_v4f64{0.0, 0.0, 0.0, 0.0};
         const cd* ap = X + (row0 + r16) * P + kq;
         const cd* bp = X + kq * P + col0 + r16;
 #pragma unroll
         for (int k0 = 0; k0 < d; k0 += 4) {
           const cd av = ap[k0], bv = bp[k0 * P];
+          sc_v4f64& acc = accs[(k0 / 4) % NACC];
           if (part == 0) {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.re, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.im, bv.im, acc, 0, 0, 0);
@@ -134,6 +149,7 @@ struct SignClipWG {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.re, acc, 0, 0, 0);
           }
         }
+        const sc_v4f64 acc = sum_chains(accs);
         double* ydst = reinterpret_cast<double*>(Y) + part;
         double rp = 0.0;
 #pragma unroll
@@ -154,7 +170,9 @@ struct SignClipWG {
       const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);  // one more quadratic step squares the error
       const double alpha = lifting ? 2.0 : 1.5, beta = lifting ? -1.0 : -0.5;
       if (mm) {  // phase 2: X_next = alpha X + beta X Yh, Yh = (Y + Y^dagger) / 2 read on the fly
-        sc_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        sc_v4f64 accs[NACC];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) accs[q] = sc_v4f64{0.0, 0.0, 0.0, 0.0};
         const cd* ap = X + (row0 + r16) * P + kq;
         const cd* bp = Y + kq * P + col0 + r16;       // Y[k][col]
         const cd* bt = Y + (col0 + r16) * P + kq;     // Y[col][k]
@@ -162,6 +180,7 @@ struct SignClipWG {
         for (int k0 = 0; k0 < d; k0 += 4) {
           const cd av = ap[k0], b0 = bp[k0 * P], b1 = bt[k0];
           const double br = 0.5 * (b0.re + b1.re), bi = 0.5 * (b0.im - b1.im);
+          sc_v4f64& acc = accs[(k0 / 4) % NACC];
           if (part == 0) {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, br, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.im, bi, acc, 0, 0, 0);
@@ -170,6 +189,7 @@ struct SignClipWG {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, br, acc, 0, 0, 0);
           }
         }
+        const sc_v4f64 acc = sum_chains(accs);
         const double* xsrc = reinterpret_cast<const double*>(X) + part;
         double* xdst = reinterpret_cast<double*>(Xn) + part;
 #pragma unroll

@@ -44,7 +44,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_PEAK_TFLOPS = 78.6  # vector FP64, SURVEY.md section 8d
+FP64_PEAK_TFLOPS = 78.6  # vector FP64 and FP64 matrix, SURVEY.md section 8d
+# what bare loops reach on this chip, measured warm in round 3 (scripts/ubench/*.hip -DQT_UBENCH_WARM; profiles/round3_ubench_*)
+FP64_MFMA_MEASURED_TFLOPS = 46.4
+VALU_WARM_NS = 2.42       # ns per FP64 wave-instruction per SIMD at four or more waves per SIMD (54.2 TFLOP/s)
+VALU_DATASHEET_NS = 4 / 2.4  # 4 cycles at 2.4 GHz
 
 
 def ginibre(rng, d):
@@ -470,9 +474,15 @@ def main():
         del big, rho_s
         if isinstance(executed, dict) and "valu_per_reconstruction" in executed and Bs == 65536:
             # executed VALU wave-instructions (PMC, committed under profiles/) against the chip's measured issue rate
-            ceil_ns = executed.get("valu_issue_ceiling_ns_per_wave_instruction_per_simd", 2.57)
-            busy_ms = executed["valu_per_reconstruction"] * Bs / 1024 * ceil_ns * 1e-6
-            executed = dict(executed, valu_issue_utilisation_at_B65536=round(busy_ms / ms, 4), mfma_utilisation=0.0)
+            # against BOTH ceilings: the data sheet's FP64 issue rate (one wave-instruction per 4 cycles
+            # at 2.4 GHz = 78.6 TFLOP/s) and the rate a bare v_fma_f64 loop reaches on this chip WARM (>= 40 ms pre-roll,
+            # >= 20 ms kernels: 54.2 TFLOP/s = 2.42 ns; profiles/round3_ubench_valu_f64_warm.txt -- 2.57 ns cold in round 1)
+            per_simd = executed["valu_per_reconstruction"] * Bs / 1024
+            executed = dict(executed,
+                            valu_issue_ceiling_ns_per_wave_instruction_per_simd=VALU_WARM_NS,
+                            valu_issue_utilisation_at_B65536=round(per_simd * VALU_WARM_NS * 1e-6 / ms, 4),
+                            valu_issue_utilisation_vs_datasheet_at_B65536=round(per_simd * VALU_DATASHEET_NS * 1e-6 / ms, 4),
+                            mfma_utilisation=0.0)
             roofline["executed_instruction_utilisation"] = executed
 
     # ---- the same steps issued alternately on two handles (two HIP streams) ----------------------
@@ -565,8 +575,16 @@ def main():
         pout = torch.empty((pb, 16, 16), dtype=torch.complex128, device="cuda")
         for cptp in (False, True):
             ms = timed(lambda: peng.lifp_dev(pc, pout, cptp=cptp), 5, peng)
+            gemm_flop = 2.0 * pb * (16 * 36) * (2 * 256)  # [B x R] . [R x 2 D^2] on v_mfma_f64_16x16x4_f64, R = 16 x 36 rows
+            tf = gemm_flop / (ms * 1e-3) / 1e12
             others["configs[2] lifp" + (" + CPTP projection" if cptp else "")] = {
-                "batch": pb, "ms_per_launch": round(ms, 4), "value": round(pb / ms * 1e3, 1), "unit": "Choi reconstructions/s"}
+                "batch": pb, "ms_per_launch": round(ms, 4), "value": round(pb / ms * 1e3, 1), "unit": "Choi reconstructions/s",
+                "mfma": {"gemm_flop": gemm_flop, "tflops_over_the_whole_call": round(tf, 2),
+                         "frac_of_peak": round(tf / FP64_PEAK_TFLOPS, 4),
+                         "frac_of_measured_ceiling": round(tf / FP64_MFMA_MEASURED_TFLOPS, 4),
+                         "note": ("the call = k_lifp_freq + k_lifp_gemm" + (" + k_cptp_project (Dykstra; its sign-function products "
+                                  "are MFMA work too, not counted here)" if cptp else "") +
+                                  "; the GEMM kernel alone: profiles/round3_*kernel_stats*")}}
         del pc, pout
         # the same at n = 3 (not a BASELINE config; 64 x 216 rows, Kronecker-factored set-up, 64 x 64 CPTP projection)
         np.random.seed(31)

@@ -196,6 +196,7 @@ struct ProcWG {
         }
         __syncthreads();
       }
+      QT_STAMP(2);
       if (pd) {
         re = ar;
         im = ai;
@@ -834,9 +835,11 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT, 4) k_cptp_project(const double
     xi = in[((size_t)b * W::NE + tid) * 2 + 1];
   }
   int it = 0;
+  QT_STAMP(0);
   if (mode == 0) it = W::dykstra(sh, act, i, j, xr, xi, n_iter, tol);
   else if (mode == 1) W::tp_project(sh, act, i, j, xr, xi);
   else W::cp_project(sh, act, i, j, xr, xi, 1e-12);
+  QT_STAMP(1);
   if (act) {
     out[((size_t)b * W::NE + tid) * 2] = xr;
     out[((size_t)b * W::NE + tid) * 2 + 1] = xi;

@@ -127,7 +127,9 @@ struct SignClipWG {
     const int tile = wave >> 1, part = wave & 1;
     const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
     const int r16 = lane & 15, kq = lane >> 4;
+    QT_STAMP(26);
     for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (identical bits in every thread)
+      QT_STAMP_VAL(25, (long long)(k + 1));  // (profile build: steps taken)
       const cd* X = reinterpret_cast<const cd*>(sm + xo);
       cd* Y = reinterpret_cast<cd*>(sm + yo);
       cd* Xn = reinterpret_cast<cd*>(sm + wo);
@@ -204,6 +206,7 @@ struct SignClipWG {
       wo = tmp;
       if (last || !(res == res)) break;
     }
+    QT_STAMP(27);
     // S = sign(A) sits in the image at xo.  R = (A + A S) / 2 + eps (I - S) / 2
     cd* S = reinterpret_cast<cd*>(sm + xo);
     cd* Y = reinterpret_cast<cd*>(sm + yo);

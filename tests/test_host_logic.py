@@ -246,6 +246,23 @@ def test_default_device_is_the_ranks_own_gpu(monkeypatch):
     assert engine.engine_key(3, device=5) == (3, 5)
     monkeypatch.setenv("QTOMO_DEVICE", "2")
     assert engine.engine_key(2) == (2, 2)
+    # a launcher that masks every rank down to ONE visible GPU (HIP_VISIBLE_DEVICES) leaves LOCAL_RANK = 3
+    # pointing at device 0 -- the default is taken modulo the visible devices, and resolved once per LOCAL_RANK value
+    monkeypatch.delenv("QTOMO_DEVICE")
+
+    class OneGpu:
+        @staticmethod
+        def qt_device_count():
+            return 1
+
+    from quantpy_amd import _capi
+
+    monkeypatch.setattr(_capi, "load", lambda: OneGpu)
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert engine.default_device() == 0 and engine.engine_key(3) == (3, 0)
+    monkeypatch.setattr(_capi, "load", lambda: type("FourGpus", (), {"qt_device_count": staticmethod(lambda: 4)}))
+    monkeypatch.setenv("LOCAL_RANK", "6")
+    assert engine.default_device() == 2
 
 
 def test_povm_tensor_guard_sees_permutations(qp, oracle):

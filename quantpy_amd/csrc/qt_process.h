@@ -696,13 +696,16 @@ __global__ void __launch_bounds__(256) k_lifp_freq(const int64_t* __restrict__ c
 // slices (at B = 1024 the 32 slices pulled 151 MB of F through L2 for a 0.6 GFLOP product -- the kernel was bound by
 // that, not by the matrix cores) and every wavefront carries two independent MFMA chains.  LDS: [Rp][16 NC] doubles
 // (147 KB at R = 576, NC = 2: one workgroup per CU, 16 x 16 = 256 workgroups at B = 1024) + the split-K scratch.
-template <int DC, int NC>
+template <int DC, int NC, int DIAG = 0>
 __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F, int B, int R, int Rp,
                                                    const double* __restrict__ pinvT, double* __restrict__ choi,
                                                    int32_t* __restrict__ status, int32_t* __restrict__ zero_iters) {
   constexpr int NE = DC * DC, N = 2 * NE, W = 16 * NC;
   extern __shared__ double s_p[];  // [Rp][W] (rows R .. Rp-1 zero), then 4 x NC x 256 doubles for the split-K sum
   const int c0 = blockIdx.x * W;
+  // DIAG (profile build only, scripts/gemm_diag.py): phases switched off at compile time to see what bounds the kernel --
+  // 1: no MFMAs, 2: no A-operand loads, 4: no slice staging, 8: no result stores.  The product is instantiated with 0.
+  constexpr int diag = DIAG;
   // Staging the slice is the longest phase of the kernel (147 KB per workgroup against ~2 us of MFMA work): eighteen
   // 16-byte loads in flight per thread -- the whole slice at R = 576 in ONE round trip to L2 (it was three rounds of
   // twelve 8-byte loads).  W is even and c0 a multiple of W, so a pair never straddles a row.
@@ -711,7 +714,7 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
 #pragma unroll
     for (int u = 0; u < 18; ++u) {
       const int e = e0 + u * 1024;
-      t[u] = e < R * W ? *reinterpret_cast<const double2*>(pinvT + (size_t)(e / W) * N + c0 + (e % W)) : double2{0.0, 0.0};
+      t[u] = (e < R * W && !(diag & 4)) ? *reinterpret_cast<const double2*>(pinvT + (size_t)(e / W) * N + c0 + (e % W)) : double2{0.0, 0.0};
     }
 #pragma unroll
     for (int u = 0; u < 18; ++u) {
@@ -757,7 +760,7 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
   for (int k0 = kbeg; k0 < kend; k0 += 64) {
     const int kn = k0 + 128 < kend ? k0 + 128 : kbeg;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) an2[j] = fr[(kn + 8 * j) / 2];
+    for (int j = 0; j < 8; ++j) an2[j] = (diag & 2) ? a[j] : fr[(kn + 8 * j) / 2];
     // all B-operand reads of the chunk first (two base addresses, immediate offsets), then the MFMA chains
     const double* b_first = s_p + (k0 + 2 * kq + (swap ? 1 : 0)) * W + r16;
     const double* b_second = s_p + (k0 + 2 * kq + (swap ? 0 : 1)) * W + r16;
@@ -774,6 +777,11 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const double lo = swap ? a[j].y : a[j].x, hi = swap ? a[j].x : a[j].y;
+      if constexpr ((diag & 1) != 0) {  // (profile build only) one vector FMA per operand pair keeps the loads alive
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c][0] = fma(lo, b0[c][j], fma(hi, b1[c][j], acc[c][0]));
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, b0[c][j], acc[c], 0, 0, 0);
 #pragma unroll
@@ -801,7 +809,7 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int orow = g * 16 + kq + 4 * r;
-        if (orow < B) {
+        if (orow < B && !((diag & 8) && n != 0)) {
           const double x = acc[c][r] + red[(c * 4 + r) * 64 + lane];
           choi[((size_t)orow * NE + er * DC + ec) * 2 + part] = x;
           if (n == 0) {  // Re C[0][0], the element k_lifp_batch tests; no projection follows when these are set

@@ -22,6 +22,9 @@
 
 namespace {
 
+#ifdef QT_PHASE_TIMING
+int g_host_diag = 0;  // profile build: compile-time variant of k_lifp_gemm to launch (qt_debug_set_diag)
+#endif
 thread_local std::string g_err;
 
 int fail(int code, const char* fmt, ...) {
@@ -1686,6 +1689,21 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
     const int nblocks = (B + 63) / 64;
     const int passes = nblocks >= 64 ? 4 : (nblocks >= 32 ? 2 : 1);
     const int row_blocks = (nblocks + passes - 1) / passes;
+#ifdef QT_PHASE_TIMING
+#define QT_GEMM_VARIANT(V)                                                                                                \
+  case V:                                                                                                                 \
+    if (int r = allow_big_lds(qt::k_lifp_gemm<16, 2, V>, gemm_lds2)) return r;                                             \
+    hipLaunchKernelGGL((qt::k_lifp_gemm<16, 2, V>), dim3(2 * NE / 32, row_blocks), dim3(512), gemm_lds2, h->stream, F, B, R, Rp, \
+                       (const double*)h->proc.pinvT, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);  \
+    break;
+    if (gemm_lds2 <= kLdsLimit && g_host_diag != 0) {
+      switch (g_host_diag) {
+        QT_GEMM_VARIANT(1) QT_GEMM_VARIANT(2) QT_GEMM_VARIANT(3) QT_GEMM_VARIANT(4) QT_GEMM_VARIANT(7) QT_GEMM_VARIANT(8)
+        QT_GEMM_VARIANT(15)
+        default: return fail(QT_ERR_ARG, "no such diagnostic variant");
+      }
+    } else
+#endif
     if (gemm_lds2 <= kLdsLimit) {  // two column tiles per workgroup: half the re-reads of F (R <= 576)
       if (int r = allow_big_lds(qt::k_lifp_gemm<16, 2>, gemm_lds2)) return r;
       hipLaunchKernelGGL((qt::k_lifp_gemm<16, 2>), dim3(2 * NE / 32, row_blocks), dim3(512), gemm_lds2, h->stream, F, B, R, Rp,
@@ -1910,6 +1928,10 @@ int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode
 }  // extern "C"
 
 #ifdef QT_PHASE_TIMING
+extern "C" int qt_debug_set_diag(int v) {  // which compile-time variant of k_lifp_gemm<16, 2> the next qt_lifp_batch launches
+  g_host_diag = v;
+  return 0;
+}
 // profile build only (scripts/phase_timing.py): where the kernels drop their phase stamps
 extern "C" int qt_debug_set_prof(void* device_ptr) {
   long long* p = static_cast<long long*>(device_ptr);

@@ -15,14 +15,19 @@ before anything in this process has touched the GPU.  Each rank reconstructs its
 (weak scaling, no data-path collective); the group size is asserted equal to --gpus and reported as
 "rccl_ranks".  After the headline the sharded legs run on every rank:
   "configs4_weak"     5-qubit MLE (configs[4]), 256 trials per rank, weak-scaled;
-  "bootstrap_ci"      the 2000-resample bootstrap CI of configs[3], strong-scaled, ONE all-gather;
-  "bootstrap_ci_n5"   the same for 5 qubits (2000 resamples), strong-scaled;
-  "bootstrap_ci_large" 2 097 152 resamples at n = 3 (a size where sharding matters), strong-scaled;
-  "bootstrap_ci_large_device_draw"  the same size, every resample distinct and drawn by its rank in HBM
-                      (qt_device_multinomial, opt-in sampler), the draw inside the timed region.
+and five STRONG-scaled bootstrap CIs (interval.py:598-612), each rank doing its shard of: [draw +] reconstruct with the
+Hilbert-Schmidt distance in the same pass (qt_mle_dist_batch) + sort of its shard + the order statistics across ranks
+(quantpy_amd.distributed.ShardedSample: two all-gathers of a few hundred KB, never the sample):
+  "bootstrap_ci"      the 2000-resample CI of configs[3] on the reference's stream (end_to_end_ms includes the serial host draw);
+  "bootstrap_ci_device_sampler"  the same with the resamples drawn in HBM (qt_device_multinomial, opt-in), draw inside the region;
+  "bootstrap_ci_n5"   2000 resamples at 5 qubits;
+  "bootstrap_ci_large" 2 097 152 resamples at n = 3 (a size where sharding matters), with "serial_ms" = what does not shard;
+  "bootstrap_ci_large_device_draw"  the same size, every resample distinct and drawn by its rank, the draw inside the region.
 
-Before the W warm-up steps the same step runs for --preroll-ms (40 ms, untimed, reported as "preroll_ms"): the counts
-were just drawn on the host, the GPU has idled into a low power state, and W x 15 us does not bring it back.
+The contract's W warm-up + K timed steps run twice: straight after the host drew the counts ("no_preroll") and again after
+--preroll-ms (40 ms, untimed, reported as "preroll_ms") of the same step, which brings the GPU back to its running clocks;
+`value` is the second.  `python bench.py --profile` regenerates profiles/round3_pmc_traffic.json (rocprofv3 PMC passes as
+child processes); `roofline.traffic` is reported only when that file was measured on this build of the library.
 
 Rank 0 prints ONE JSON line (contract in the task statement) that also carries
   "roofline":     the dominant kernel against the HBM roofline, from HIP-event timing of

@@ -105,15 +105,16 @@ def allgather_device(local, n_total):
     return torch.cat([out[r * width: r * width + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
 
 
-def allgather_equal(x):
+def allgather_equal(x, force_collective=False):
     """Stack the ranks' equally shaped tensors / arrays along a new first axis: (N, *x.shape) on every rank.  torch CUDA
     tensors travel as ONE RCCL all-gather on torch's current stream (`nccl` group) or through the host (`gloo`);
-    NumPy arrays come back as NumPy arrays."""
+    NumPy arrays come back as NumPy arrays.  A one-rank group returns `x[None]` without a collective unless
+    `force_collective` (the rehearsal of the RCCL calls on a one-GPU box: tests/test_gpu_selection.py)."""
     import torch
 
     dist = _dist()
     is_np = isinstance(x, np.ndarray)
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None or (dist.get_world_size() == 1 and not force_collective):
         return x[None]
     ws = dist.get_world_size()
     if dist.get_backend() == "nccl":

@@ -326,3 +326,48 @@ def test_bootstrap_interval_shards_over_ranks_with_identical_quantiles(tmp_path)
         assert a[key]["n"] == b[key]["n"] and a[key]["sorted_ok"] and b[key]["sorted_ok"]
         assert a[key]["path"] == "local" and b[key]["shard"] == -(-a[key]["n"] // 2)
     assert b["device-lin-30000"]["path"] == "selection"
+
+
+_RCCL_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from quantpy_amd import distributed as qd
+torch.cuda.set_device(0)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29751")
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and qd.world() == (0, 1)
+# the exchanges of ShardedSample / BootstrapStateInterval as RCCL issues them, on a one-rank group
+spl = torch.arange(3856, dtype=torch.float64, device="cuda") * 0.5
+got = qd.allgather_equal(spl, force_collective=True)
+assert got.shape == (1, 3856) and got.is_cuda and torch.equal(got[0], spl)
+win = torch.rand((3, 2 + 1292), dtype=torch.float64, device="cuda")
+got = qd.allgather_equal(win, force_collective=True)
+assert got.shape == (1, 3, 1294) and torch.equal(got[0], win)
+keys = np.array([0, 2**63 - 1, -1, 12345], dtype=np.int64)             # bit patterns travel as int64
+got = qd.allgather_equal(keys, force_collective=True)
+assert isinstance(got, np.ndarray) and got.dtype == np.int64 and np.array_equal(got[0], keys)
+bad = qd.allgather_equal(np.array([0, 1]), force_collective=True).max(axis=0)
+assert bad.tolist() == [0, 1]
+seed = np.array([0xDEADBEEFCAFEF00D], dtype=np.uint64)
+assert int(qd.broadcast_array(seed.view(np.int64)).view(np.uint64)[0]) == 0xDEADBEEFCAFEF00D
+full = qd.allgather_device(torch.arange(5, dtype=torch.float64, device="cuda"), 5)
+assert full.shape == (5,)
+torch.cuda.synchronize()
+print("rccl ok", flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_the_collectives_of_the_sharded_path_on_a_one_rank_rccl_group(tmp_path):
+    """No multi-GPU box here: the RCCL calls the N > 1 path makes (all_gather_into_tensor of float64 / int64 device tensors
+    on torch's current stream, NumPy payloads through the device) are at least issued for real, on a one-rank nccl group."""
+    script = tmp_path / "worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    res = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "rccl ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]

@@ -21,6 +21,8 @@ namespace qt {
 struct ProcessState {
   void* lifp = nullptr;      // [D*M][D^2] complex design matrix
   void* pinvT = nullptr;     // [D*M][D^2] complex: transpose of its left inverse
+  void* pinvR = nullptr;     // the same with each row's D^2 entries in ROW-major Choi order (k_lifp_gemm's operand: its product
+                             // columns are then the doubles of choi[b] in order); built for n = 2 only
   void* emats = nullptr;     // [M][d][d] complex POVM elements
   void* in_states = nullptr; // [D][d][d] complex
   void* aug = nullptr;       // [D^2][2 D^2] complex Gauss-Jordan workspace
@@ -33,7 +35,7 @@ struct ProcessState {
   size_t cap_rows = 0;
   void release() {
     factored = false;
-    for (void** p : {&lifp, &pinvT, &emats, &in_states, &aug, &pinv, &vs_pinv, &vp_pinv, &vp_pinvT}) {
+    for (void** p : {&lifp, &pinvT, &pinvR, &emats, &in_states, &aug, &pinv, &vs_pinv, &vp_pinv, &vp_pinvT}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
@@ -663,6 +665,23 @@ __global__ void __launch_bounds__(ProcWG<DC>::NT, 2) k_mhmc_process(const int64_
 // LDS ([R][16] doubles, 74 KB at R = 576) and its wavefronts take 16 processes at a time through
 // v_mfma_f64_16x16x4_f64, streaming their frequency rows as the A operand (64 k-values requested ahead).
 //
+// pinvR[r][er DC + ec] = pinvT[r][ec DC + er] (complex): the column-stacked Choi vector of routines.py:59-61 re-ordered
+// to the row-major matrix, once per set-up, so that the GEMM below writes choi[b] as contiguous 128-byte runs AND stages
+// contiguous operand slices.  Measured at B = 1024 (k_lifp_freq + k_lifp_gemm per call): 34-36 us with the column-stacked
+// operand (16-byte result pieces 256 bytes apart), 40 us when the slices were gathered on the fly from pinvT instead
+// (eight times the L2 lines per slice), 32 us with this copy.  Also tried on top and dropped: the frequencies formed
+// inside the GEMM's A-operand path from the raw counts and per-state inverse totals (no k_lifp_freq launch, no
+// frequency matrix): 34 us -- the int64 -> double conversions and the scaling sit in the MFMA loop at 256 VGPRs.
+__global__ void k_choi_order_rows(const double* __restrict__ pinvT, size_t rows, int DC, double* __restrict__ pinvR) {
+  const size_t ne = (size_t)DC * DC, total = rows * ne;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = t / ne, v = t % ne;
+    const size_t er = v / DC, ec = v % DC;
+    const double2 x = *reinterpret_cast<const double2*>(pinvT + (r * ne + ec * DC + er) * 2);
+    *reinterpret_cast<double2*>(pinvR + t * 2) = x;
+  }
+}
+
 // Step 1: counts [B][DC][M] -> frequencies [B][R = DC M], normalised per input state (process.py:285);
 // 16 lanes per (process, input state) row.
 __global__ void __launch_bounds__(256) k_lifp_freq(const int64_t* __restrict__ counts, int rows, int M, int DC, int Rp,
@@ -698,10 +717,12 @@ __global__ void __launch_bounds__(256) k_lifp_freq(const int64_t* __restrict__ c
 // (147 KB at R = 576, NC = 2: one workgroup per CU, 16 x 16 = 256 workgroups at B = 1024) + the split-K scratch.
 template <int DC, int NC, int DIAG = 0>
 __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F, int B, int R, int Rp,
-                                                   const double* __restrict__ pinvT, double* __restrict__ choi,
+                                                   const double* __restrict__ pinvR, double* __restrict__ choi,
                                                    int32_t* __restrict__ status, int32_t* __restrict__ zero_iters) {
   constexpr int NE = DC * DC, N = 2 * NE, W = 16 * NC;
   extern __shared__ double s_p[];  // [Rp][W] (rows R .. Rp-1 zero), then 4 x NC x 256 doubles for the split-K sum
+  // The operand is pinvR: product column n is double n of choi[b] (row-major, re / im interleaved), so a workgroup's
+  // W columns are a contiguous run of a Choi row and a wavefront's results go out as 128-byte runs (round 3).
   const int c0 = blockIdx.x * W;
   // DIAG (profile build only, scripts/gemm_diag.py): phases switched off at compile time to see what bounds the kernel --
   // 1: no MFMAs, 2: no A-operand loads, 4: no slice staging, 8: no result stores.  The product is instantiated with 0.
@@ -714,7 +735,7 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
 #pragma unroll
     for (int u = 0; u < 18; ++u) {
       const int e = e0 + u * 1024;
-      t[u] = (e < R * W && !(diag & 4)) ? *reinterpret_cast<const double2*>(pinvT + (size_t)(e / W) * N + c0 + (e % W)) : double2{0.0, 0.0};
+      t[u] = (e < R * W && !(diag & 4)) ? *reinterpret_cast<const double2*>(pinvR + (size_t)(e / W) * N + c0 + (e % W)) : double2{0.0, 0.0};
     }
 #pragma unroll
     for (int u = 0; u < 18; ++u) {
@@ -804,14 +825,13 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
   if (!half) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const int n = c0 + 16 * c + r16, v = n >> 1, part = n & 1;
-      const int er = v % DC, ec = v / DC;
+      const int n = c0 + 16 * c + r16;  // double n of the process's Choi matrix
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int orow = g * 16 + kq + 4 * r;
         if (orow < B && !((diag & 8) && n != 0)) {
           const double x = acc[c][r] + red[(c * 4 + r) * 64 + lane];
-          choi[((size_t)orow * NE + er * DC + ec) * 2 + part] = x;
+          choi[(size_t)orow * N + n] = x;
           if (n == 0) {  // Re C[0][0], the element k_lifp_batch tests; no projection follows when these are set
             if (status) status[orow] = (x == x) ? 0 : 4;
             if (zero_iters) zero_iters[orow] = 0;

@@ -1587,6 +1587,11 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
   hipLaunchKernelGGL(qt::k_gemm<1>, gp, dim3(64), 0, h->stream, c2, rr, c2, aug + (size_t)c2 * 2, 2 * c2, 0, lifp, c2, 1,
                      pinv, rr);
   launch_transpose<2>(h, pinv, c2, rr, pinvT);
+  if (h->nq == 2) {  // the batched GEMM of qt_lifp_batch reads the left inverse in row-major Choi order
+    HIPCHK(hipMalloc(&ps.pinvR, R * C2 * 2 * sizeof(double)));
+    hipLaunchKernelGGL(qt::k_choi_order_rows, dim3(grid_for(R * C2)), dim3(256), 0, h->stream, (const double*)pinvT, R, D,
+                       (double*)ps.pinvR);
+  }
   int info = 0;
   HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipGetLastError());
@@ -1694,7 +1699,7 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
   case V:                                                                                                                 \
     if (int r = allow_big_lds(qt::k_lifp_gemm<16, 2, V>, gemm_lds2)) return r;                                             \
     hipLaunchKernelGGL((qt::k_lifp_gemm<16, 2, V>), dim3(2 * NE / 32, row_blocks), dim3(512), gemm_lds2, h->stream, F, B, R, Rp, \
-                       (const double*)h->proc.pinvT, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);  \
+                       (const double*)h->proc.pinvR, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);  \
     break;
     if (gemm_lds2 <= kLdsLimit && g_host_diag != 0) {
       switch (g_host_diag) {
@@ -1707,11 +1712,11 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
     if (gemm_lds2 <= kLdsLimit) {  // two column tiles per workgroup: half the re-reads of F (R <= 576)
       if (int r = allow_big_lds(qt::k_lifp_gemm<16, 2>, gemm_lds2)) return r;
       hipLaunchKernelGGL((qt::k_lifp_gemm<16, 2>), dim3(2 * NE / 32, row_blocks), dim3(512), gemm_lds2, h->stream, F, B, R, Rp,
-                         (const double*)h->proc.pinvT, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
+                         (const double*)h->proc.pinvR, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
     } else {
       if (int r = allow_big_lds(qt::k_lifp_gemm<16, 1>, gemm_lds)) return r;
       hipLaunchKernelGGL((qt::k_lifp_gemm<16, 1>), dim3(2 * NE / 16, row_blocks), dim3(512), gemm_lds, h->stream, F, B, R, Rp,
-                         (const double*)h->proc.pinvT, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
+                         (const double*)h->proc.pinvR, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
     }
     if (cptp)
       hipLaunchKernelGGL(qt::k_cptp_project<16>, dim3(B), dim3(qt::ProcWG<16>::NT), 0, h->stream, (const double*)raw, B, 0,

@@ -174,7 +174,10 @@ def run_profile():
     env = dict(os.environ, TMPDIR="/tmp")
     me = os.path.abspath(__file__)
     passes = {"stats": ["--kernel-trace", "--stats"], "fetch": ["--kernel-trace", "--pmc", "FETCH_SIZE"],
-              "write": ["--kernel-trace", "--pmc", "WRITE_SIZE"]}
+              "write": ["--kernel-trace", "--pmc", "WRITE_SIZE"],
+              # executed wave-instructions of the n = 3 kernels (SQ block: eight counter slots per pass, five used)
+              "sq": ["--kernel-trace", "--pmc", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VALU_MFMA_MOPS_F64",
+                     "SQ_WAVES"]}
     for name, flags in passes.items():
         cmd = ["rocprofv3", *flags, "-d", os.path.join(out_root, name), "-o", "run", "--output-format", "csv", "--",
                sys.executable, me, *SHORT_FLAGS, "--saturation-batch", "65536"]
@@ -194,6 +197,8 @@ def run_profile():
         return per
 
     fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
+    sq = {name: counter("sq", name) for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VALU_MFMA_MOPS_F64",
+                                                  "SQ_WAVES")}
     fused = "qt::k_mle_fused<3, false>"
     start = "qt::k_mle_start<3, false>"
     m_rows, d_el = 216, 64
@@ -210,7 +215,24 @@ def run_profile():
     avg_ns = {r["Name"].split("(")[0].replace("void ", ""): (float(r["AverageNs"]), int(r["Calls"])) for r in stats_rows}
     f_kib, w_kib = statistics.median(fetch[fused]), statistics.median(write[fused])
     f_bytes = f_kib * 1024.0 * (cal if cal else 1.0)
+    executed = None
+    if start in sq["SQ_WAVES"] and sq["SQ_WAVES"][start]:
+        # the 65 536-trial launches of k_mle_start<3>: one trial per wavefront, the whole nit = 0 path of a reconstruction
+        waves = statistics.median(sq["SQ_WAVES"][start])
+        per = {k: statistics.median(v[start]) / waves for k, v in sq.items() if start in v and k != "SQ_WAVES"}
+        executed = {
+            "source": "python bench.py --profile: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS "
+                      "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES (one pass) over the saturated launches of " + start +
+                      " = the whole nit = 0 path of one reconstruction per wavefront",
+            "waves_per_launch": waves,
+            "valu_per_reconstruction": round(per.get("SQ_INSTS_VALU", 0.0), 1),
+            "salu_per_reconstruction": round(per.get("SQ_INSTS_SALU", 0.0), 1),
+            "lds_per_reconstruction": round(per.get("SQ_INSTS_LDS", 0.0), 1),
+            "mfma_f64_ops": round(per.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0), 1),
+            "note": "the n <= 3 estimators execute no MFMA instruction: the contractions are factorised (8x fewer flops than "
+                    "the dense GEMM form) and account for ~13 % of the VALU instructions (DESIGN.md 4.3)"}
     res = {
+        "executed": executed,
         "source": "python bench.py --profile: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and "
                   "--kernel-trace --stats over `bench.py " + " ".join(SHORT_FLAGS) + " --saturation-batch 65536`",
         "library_srchash": library_hash(),
@@ -431,14 +453,17 @@ def main():
             traffic = pmc["traffic_bytes_per_launch"]
             traffic_src = (f"profiles/{PMC_FILE} (python bench.py --profile: rocprofv3 --pmc FETCH_SIZE x calibration "
                            f"{pmc['fetch_calibration']['factor']:.3f} + WRITE_SIZE; same library source hash)")
+            executed = pmc.get("executed")  # instruction counts of the same build (SQ pass of --profile)
         else:
             traffic_src = f"profiles/{PMC_FILE} was measured on another build of the library (source hash differs): not reported"
-    exec_file = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
-    if os.path.exists(exec_file):
-        with open(exec_file) as fh:
-            executed = json.load(fh).get("executed")
-        if isinstance(executed, dict):
-            executed = dict(executed, measured_on="round-2 build of k_mle_start<3> (instruction counts per reconstruction)")
+    if executed is None:
+        exec_file = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
+        if os.path.exists(exec_file):
+            with open(exec_file) as fh:
+                executed = json.load(fh).get("executed")
+            if isinstance(executed, dict):
+                executed = dict(executed, measured_on="round-2 build of k_mle_start<3> (instruction counts per reconstruction): "
+                                                      "no SQ pass of this build under profiles/")
     # qt_mle_batch runs the single-launch kernel while the batch fits one wave per SIMD (<= 1024 waves)
     dominant_kernel = ("qt::k_mle_fused<3,false>" if B <= 1024 else
                        "qt::k_mle_start<3,false> (+ qt::k_mle_bfgs<3,false> for the trials that iterate)")

@@ -107,7 +107,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world_size", [2, 3])
+@pytest.mark.parametrize("world_size", [2, 3, 4])
 def test_sharded_quantiles_equal_sort_plus_interp1d_gloo(tmp_path, world_size):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)

@@ -248,11 +248,34 @@ QT_SAMPLER_HD inline void legacy_multinomial(G& g, int64_t n, const double* pval
   if (dn > 0) out[K - 1] = dn;
 }
 
+// One row of the opt-in device sampler: multinomial(n_s, p[0..K)) drawn from the Philox stream (seed, global row) by the
+// conditional-binomial chain above, each conditional probability clamped into [0, 1] (rounding can leave it a hair above 1;
+// a NaN must not reach the rejection loop).  Host and device: tests/test_gpu_device_sampler.py runs the host instantiation
+// (tests/host/sampler_host.cpp) beside the kernel on the same streams -- same template, same uniforms, same counts.
+QT_SAMPLER_HD inline void philox_multinomial_row(uint64_t seed, uint64_t global_row, int64_t n_s, const double* p, int K,
+                                                  int64_t* o) {
+  Philox g(seed, global_row, 0u);
+  BinomialSetup setup;
+  double remaining_p = 1.0;
+  int64_t dn = n_s;
+  int j = 0;
+  for (; j < K - 1 && dn > 0; ++j) {
+    const double pj = p[j];
+    double pc = pj / remaining_p;
+    pc = pc >= 0.0 ? (pc <= 1.0 ? pc : 1.0) : 0.0;
+    const int64_t x = legacy_binomial(g, pc, dn, setup);
+    o[j] = x;
+    dn -= x;
+    remaining_p -= pj;
+  }
+  for (; j < K - 1; ++j) o[j] = 0;
+  o[K - 1] = dn > 0 ? dn : 0;
+}
+
 #if defined(__HIPCC__)
 // Opt-in device sampler: row r (= resample r / period, setting r % period) is drawn by one thread from its own Philox
 // stream (seed, first_row + r), so the counts of a row depend on nothing but (seed, global row index, n, p): any
-// split of the rows over launches or ranks gives the same table.  The same conditional-binomial chain as above;
-// out is [rows][K] int64, what the estimators read.
+// split of the rows over launches or ranks gives the same table.  out is [rows][K] int64, what the estimators read.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_multinomial_rows(uint64_t seed, uint64_t first_row, long long rows, int period,
                                                           const int64_t* __restrict__ n, const double* __restrict__ pvals,
                                                           int K, int64_t* __restrict__ out) {
@@ -263,24 +286,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   const long long r = (gid / span * 64 + (gid % span) % 64) * period + (gid % span) / 64;
   if (r >= rows) return;
   const int s = (int)((first_row + (uint64_t)r) % (uint64_t)period);
-  Philox g(seed, first_row + (uint64_t)r, 0u);
-  const double* p = pvals + (size_t)s * K;
-  int64_t* o = out + (size_t)r * K;
-  BinomialSetup setup;
-  double remaining_p = 1.0;
-  int64_t dn = n[s];
-  int j = 0;
-  for (; j < K - 1 && dn > 0; ++j) {
-    const double pj = p[j];
-    double pc = pj / remaining_p;  // rounding can leave it a hair above 1; a NaN must not reach the rejection loop
-    pc = pc >= 0.0 ? (pc <= 1.0 ? pc : 1.0) : 0.0;
-    const int64_t x = legacy_binomial(g, pc, dn, setup);
-    o[j] = x;
-    dn -= x;
-    remaining_p -= pj;
-  }
-  for (; j < K - 1; ++j) o[j] = 0;
-  o[K - 1] = dn > 0 ? dn : 0;
+  philox_multinomial_row(seed, first_row + (uint64_t)r, n[s], pvals + (size_t)s * K, K, out + (size_t)r * K);
 }
 
 #endif  // __HIPCC__

@@ -25,6 +25,14 @@ int qt_host_legacy_multinomial(uint32_t* mt_key, int* mt_pos, long long rows, in
   *mt_pos = g.pos;
   return 0;
 }
+// the rows of qt_device_multinomial on the host: same template, same Philox streams (checker of the device kernel)
+void qt_host_philox_multinomial(uint64_t seed, uint64_t first_row, long long rows, int period, const int64_t* n,
+                                const double* pvals, int K, int64_t* out) {
+  for (long long r = 0; r < rows; ++r) {
+    const int s = (int)((first_row + (uint64_t)r) % (uint64_t)period);
+    qt_sampler::philox_multinomial_row(seed, first_row + (uint64_t)r, n[s], pvals + (size_t)s * K, K, out + (size_t)r * K);
+  }
+}
 // the Philox block of the device sampler (known-answer vectors)
 void qt_host_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { qt_sampler::philox4x32_10(ctr, key, out); }
 }

@@ -153,3 +153,54 @@ def test_tomograph_and_bootstrap_with_device_sampler():
         ci = qp.BootstrapProcessInterval(pt, n_points=200, sampler="device", seed=4)
         d, _ = ci(levels)
         assert np.all(np.isfinite(d)) and np.all(np.diff(d) >= 0)
+
+
+def test_device_rows_equal_the_host_instantiation_on_the_same_philox_streams(eng, tmp_path):
+    """The device sampler has no reference parity by construction (its streams are not NumPy's).  What CAN be pinned: the
+    kernel runs the very template the host runs -- `philox_multinomial_row` over `legacy_binomial` -- and the host
+    instantiation of those binomial routines on NumPy's MT19937 words IS NumPy's sampler bit for bit
+    (tests/test_host_logic.py).  Same (seed, row) streams on both sides: the counts must be identical, in the inversion
+    regime, in BTPE, across the p > 0.5 reflection, with structural zeros and for ragged shot vectors.  (libm and the
+    device's log / exp / sqrt differ in the last place at most: a draw flips only if a uniform falls within ~1e-16 of a
+    bound.)"""
+    import ctypes
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libsampler_host.so")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so,
+                           os.path.join(root, "tests", "host", "sampler_host.cpp")])
+    host = ctypes.CDLL(so)
+    host.qt_host_philox_multinomial.restype = None
+    host.qt_host_philox_multinomial.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(17)
+    total = 0
+    for case in range(12):
+        period, k = int(rng.integers(1, 28)), int(rng.integers(2, 9))
+        p = rng.random((period, k)) ** (1 + 2 * (case % 3))
+        if case % 4 == 1:
+            p[rng.random((period, k)) < 0.3] = 0.0
+            p[:, 0] += 1e-6
+        if case % 4 == 2:
+            p[:, 0] += 5.0  # the first conditional probability > 0.5: reflection branch
+        p /= p.sum(1, keepdims=True)
+        n = rng.integers(1, [30, 2000, 10**5, 10**7][case % 4], period).astype(np.int64)
+        rows = int(rng.integers(1, 40)) * period + int(rng.integers(0, period))
+        seed, first = int(rng.integers(0, 2**62)), int(rng.integers(0, 10**6))
+        got = eng.device_multinomial(n, p, rows, seed, first_row=first)
+        want = np.empty_like(got)
+        pc = np.ascontiguousarray(p)
+        host.qt_host_philox_multinomial(seed, first, rows, period, n.ctypes.data, pc.ctypes.data, k, want.ctypes.data)
+        assert np.array_equal(got, want), (case, int((got != want).any(1).sum()), rows)
+        total += rows
+    # the bootstrap's own shape: 27 settings x 8 outcomes at 1e5 shots, 2000 resamples
+    p = rng.random((27, 8))
+    p /= p.sum(1, keepdims=True)
+    n = np.full(27, 100000, dtype=np.int64)
+    got = eng.device_multinomial(n, p, 54000, 4242)
+    want = np.empty_like(got)
+    host.qt_host_philox_multinomial(4242, 0, 54000, 27, n.ctypes.data, p.ctypes.data, 8, want.ctypes.data)
+    assert np.array_equal(got, want)
+    assert total > 500

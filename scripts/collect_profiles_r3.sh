@@ -38,7 +38,8 @@ step "phase stamps (profile build)"
 QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing_large.py 5 256 > $OUT/${TAG}_phase_timing_n5.txt 2>&1
 { QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing_cptp.py 1024; QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing_cptp.py 256; } > $OUT/${TAG}_phase_timing_cptp.txt 2>&1
 QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing.py > $OUT/${TAG}_phase_timing_B1000.txt 2>&1
+QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/gemm_diag.py > $OUT/${TAG}_gemm_phase_switches.txt 2>&1
 step "parity sweeps"
-timeout -k 10 600 python3 scripts/parity_sweep.py 8 > $OUT/${TAG}_parity_sweep.txt 2>&1; tail -2 $OUT/${TAG}_parity_sweep.txt
-timeout -k 10 600 python3 scripts/parity_sweep.py 4 split > $OUT/${TAG}_parity_sweep_split.txt 2>&1; tail -2 $OUT/${TAG}_parity_sweep_split.txt
+timeout -k 10 900 python3 scripts/parity_sweep.py 24 > $OUT/${TAG}_parity_sweep.txt 2>&1; tail -2 $OUT/${TAG}_parity_sweep.txt
+timeout -k 10 900 python3 scripts/parity_sweep.py 8 split > $OUT/${TAG}_parity_sweep_split.txt 2>&1; tail -2 $OUT/${TAG}_parity_sweep_split.txt
 step done

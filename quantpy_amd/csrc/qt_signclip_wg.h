@@ -17,9 +17,15 @@
 // needs a fallback.  Y is re-symmetrised when it is read (one extra LDS read), which keeps rounding from feeding
 // a non-Hermitian component.  Agreement with LAPACK-eigh clipping: ~1e-15 (tests/test_gpu_large.py).
 //
-// Complex product C = A B on the matrix cores: one wavefront per (16 x 16 tile of C, real | imaginary part); the real
-// part accumulates Ar Br - Ai Bi, the imaginary one Ar Bi + Ai Br, over K in steps of 4 (operand layout as k_gemm,
-// qt_ops.h).  Images are complex interleaved with row pitch d + 1 (conflict-free 16-byte operand reads).
+// Complex product C = A B on the matrix cores, THREE real products per tile (round 3): one wavefront per 16 x 16 tile of
+// C accumulates P1 = Ar Br, P2 = Ai Bi and P3 = (Ar + Ai)(Br + Bi) over K in steps of 4 (operand layout as k_gemm,
+// qt_ops.h) -- three independent MFMA chains -- and forms Cr = P1 - P2, Ci = P3 - P1 - P2 in its accumulators.  The iteration
+// is bound by the throughput of the FP64 matrix pipe (one v_mfma_f64_16x16x4_f64 per ~88 clocks per SIMD):
+// 96 instead of 128 instructions per 32 x 32 product, on four wavefronts (one per SIMD) instead of eight, and the lane that
+// holds a result holds both of its parts (16-byte stores, the residual and the epilogue need no second wavefront).  The
+// imaginary part carries a rounding error of order eps (|Ar| + |Ai|)(|Br| + |Bi|) instead of eps (|Ar||Bi| + |Ai||Br|):
+// normwise the same, and the clip agrees with an eigh-based one as before (tests/test_gpu_large.py, test_gpu_fullsize.py).
+// Images are complex interleaved with row pitch d + 1 (conflict-free 16-byte operand reads).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,16 +49,41 @@ struct SignClipWG {
     int img0, img1, img2, red;
   };
 
+  // d = 32: three real products per tile on one wavefront (above).  d = 16 keeps four products on two wavefronts (real |
+  // imaginary part): its kernels sit at the 128-register step of four workgroups per CU and the third accumulator tile pushed
+  // them over it (k_mle_large_start<4>: 119 VGPRs + 24 AGPRs, three workgroups per CU), and a d = 16 step is not bound by the
+  // matrix pipe's throughput in the first place (profiles/round3_phase_timing_cptp.txt).
+  static constexpr bool kThreeMult = d >= 32;
   // Independent accumulator chains per product tile.  A dependent v_mfma_f64_16x16x4_f64 costs ~170 clocks of latency
   // against ~16 of issue (profiles/round3_ubench_mfma_f64_warm.txt: one chain per wavefront runs the matrix pipe at 27 of
   // its 46 TFLOP/s), and since round 3 a step of the iteration IS two such chains plus two barriers: the d / 4 k-steps of
   // a tile are dealt round-robin to NACC accumulators and summed at the end.  Registers: 8 per chain.
-  static constexpr int NACC = d >= 32 ? 4 : 2;
+  static constexpr int NACC = 2;
   __device__ __forceinline__ static sc_v4f64 sum_chains(const sc_v4f64 (&a)[NACC]) {
     sc_v4f64 s = a[0];
 #pragma unroll
     for (int q = 1; q < NACC; ++q) s += a[q];
     return s;
+  }
+
+  // One tile's three real products over the whole K range: lane (r16, kq) feeds A[row0 + r16][k0 + kq] and
+  // B[k0 + kq][col0 + r16] (B through `bload`, which may symmetrise on the fly) and ends with rows kq + 4 r of column r16.
+  struct Tile3 {
+    sc_v4f64 p1, p2, p3;
+    __device__ __forceinline__ double re(int r) const { return p1[r] - p2[r]; }
+    __device__ __forceinline__ double im(int r) const { return p3[r] - p1[r] - p2[r]; }
+  };
+  template <class BLoad>
+  __device__ __forceinline__ static Tile3 tile_product(const cd* ap, BLoad bload) {
+    Tile3 t{sc_v4f64{0.0, 0.0, 0.0, 0.0}, sc_v4f64{0.0, 0.0, 0.0, 0.0}, sc_v4f64{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int k0 = 0; k0 < d; k0 += 4) {
+      const cd a = ap[k0], b = bload(k0);
+      t.p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, t.p1, 0, 0, 0);
+      t.p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.im, t.p2, 0, 0, 0);
+      t.p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, b.re + b.im, t.p3, 0, 0, 0);
+    }
+    return t;
   }
 
   __device__ static double wsum(double* red, double v) {  // identical bits in every thread
@@ -68,32 +99,45 @@ struct SignClipWG {
 
   // C = A * B.  Ends with a barrier: C is visible to every thread, A and B may be overwritten.
   __device__ static void matmul(const cd* A, const cd* B, cd* C) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave < 2 * NTILE) {  // wave-uniform
-      const int tile = wave >> 1, part = wave & 1;
-      const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
-      const int r16 = lane & 15, kq = lane >> 4;
-      // (one accumulator: a second chain -- one per real product -- was measured: no change at d = 32, and the 16 x 16
-      //  kernels came out 20 % slower end to end, k_mle_large_start<4> 0.100 -> 0.123 ms per 1024)
-      sc_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-      const cd* ap = A + (row0 + r16) * P + kq;
-      const cd* bp = B + kq * P + col0 + r16;
-#pragma unroll
-      for (int k0 = 0; k0 < d; k0 += 4) {
-        const cd a = ap[k0], b = bp[k0 * P];
-        if (part == 0) {
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, acc, 0, 0, 0);
-        } else {
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, acc, 0, 0, 0);
-        }
+    if constexpr (kThreeMult) {
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      if (wave < NTILE) {  // wave-uniform
+        const int row0 = (wave / TPR) * 16, col0 = (wave % TPR) * 16;
+        const int r16 = lane & 15, kq = lane >> 4;
+        const cd* bp = B + kq * P + col0 + r16;
+        const Tile3 t = tile_product(A + (row0 + r16) * P + kq, [&](int k0) { return bp[k0 * P]; });
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) C[(row0 + kq + 4 * r) * P + col0 + r16] = cd{t.re(r), t.im(r)};
       }
-      double* cdst = reinterpret_cast<double*>(C) + part;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cdst[((row0 + kq + 4 * r) * P + col0 + r16) * 2] = acc[r];
+      __syncthreads();
+    } else {
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      if (wave < 2 * NTILE) {  // wave-uniform
+        const int tile = wave >> 1, part = wave & 1;
+        const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
+        const int r16 = lane & 15, kq = lane >> 4;
+        // (one accumulator: a second chain -- one per real product -- was measured: no change at d = 32, and the 16 x 16
+        //  kernels came out 20 % slower end to end, k_mle_large_start<4> 0.100 -> 0.123 ms per 1024)
+        sc_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        const cd* ap = A + (row0 + r16) * P + kq;
+        const cd* bp = B + kq * P + col0 + r16;
+  #pragma unroll
+        for (int k0 = 0; k0 < d; k0 += 4) {
+          const cd a = ap[k0], b = bp[k0 * P];
+          if (part == 0) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, acc, 0, 0, 0);
+          } else {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, acc, 0, 0, 0);
+          }
+        }
+        double* cdst = reinterpret_cast<double*>(C) + part;
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) cdst[((row0 + kq + 4 * r) * P + col0 + r16) * 2] = acc[r];
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // In: this thread's element of a Hermitian matrix.  Out: its element of U max(lambda, eps) U^dagger (/ trace).
@@ -120,91 +164,147 @@ struct SignClipWG {
     // Round 3: a step is TWO barrier-separated phases on the wavefronts that own the product tiles (it was five, with
     // every thread of the workgroup reading Y, reducing res and writing W in between): the residual comes out of the
     // accumulators of Y = X^2, and X (alpha I + beta Y) = alpha X + beta X Y is finished in the accumulators of the
-    // second product, whose B operand is the Hermitian part of Y taken on the fly.  At d = 32 a step was ~5 k clocks of
-    // mostly barrier and LDS round-trip latency, ~25 steps per clipped trial (130 k of its 319 k clocks).
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool mm = wave < 2 * NTILE;  // wave-uniform
-    const int tile = wave >> 1, part = wave & 1;
-    const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
-    const int r16 = lane & 15, kq = lane >> 4;
-    QT_STAMP(26);
-    for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (identical bits in every thread)
-      QT_STAMP_VAL(25, (long long)(k + 1));  // (profile build: steps taken)
-      const cd* X = reinterpret_cast<const cd*>(sm + xo);
-      cd* Y = reinterpret_cast<cd*>(sm + yo);
-      cd* Xn = reinterpret_cast<cd*>(sm + wo);
-      if (mm) {  // phase 1: Y = X X, and this tile's share of res = ||I - Y||_F^2
-        sc_v4f64 accs[NACC];
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) accs[q] = sc_v4f64{0.0, 0.0, 0.0, 0.0};
-        const cd* ap = X + (row0 + r16) * P + kq;
-        const cd* bp = X + kq * P + col0 + r16;
-#pragma unroll
-        for (int k0 = 0; k0 < d; k0 += 4) {
-          const cd av = ap[k0], bv = bp[k0 * P];
-          sc_v4f64& acc = accs[(k0 / 4) % NACC];
-          if (part == 0) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.re, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.im, bv.im, acc, 0, 0, 0);
-          } else {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.im, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.re, acc, 0, 0, 0);
+    // second product, whose B operand is the Hermitian part of Y taken on the fly.  Measured (profiles/round3_phase_timing_*):
+    // that alone moved nothing at d = 32 -- 127 k clocks per clip as before -- because the ~50 products of a clip are bound by
+    // the matrix pipe's throughput, not by barriers; what moved it is fewer MFMAs per product (tile_product above).
+    if constexpr (kThreeMult) {
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      const bool mm = wave < NTILE;  // wave-uniform: one wavefront per tile (d = 32: one per SIMD)
+      const int row0 = (wave / TPR) * 16, col0 = (wave % TPR) * 16;
+      const int r16 = lane & 15, kq = lane >> 4;
+      QT_STAMP(26);
+      for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (identical bits in every thread)
+        QT_STAMP_VAL(25, (long long)(k + 1));  // (profile build: steps taken)
+        const cd* X = reinterpret_cast<const cd*>(sm + xo);
+        cd* Y = reinterpret_cast<cd*>(sm + yo);
+        cd* Xn = reinterpret_cast<cd*>(sm + wo);
+        if (mm) {  // phase 1: Y = X X, and this tile's share of res = ||I - Y||_F^2
+          const cd* bp = X + kq * P + col0 + r16;
+          const Tile3 t = tile_product(X + (row0 + r16) * P + kq, [&](int k0) { return bp[k0 * P]; });
+          double rp = 0.0;
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = row0 + kq + 4 * r, col = col0 + r16;
+            const double yr = t.re(r), yi = t.im(r);
+            Y[row * P + col] = cd{yr, yi};
+            const double dv = (row == col) ? 1.0 - yr : yr;
+            rp = fma(dv, dv, fma(yi, yi, rp));
+          }
+          rp = gsum<64>(rp);
+          if (lane == 0) red[wave] = rp;
+        }
+        __syncthreads();
+        double res = 0.0;
+  #pragma unroll
+        for (int w = 0; w < NTILE; ++w) res += red[w];
+        if (lifting && (res < 0.5 || k >= 40)) lifting = false;
+        const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);  // one more quadratic step squares the error
+        const double alpha = lifting ? 2.0 : 1.5, beta = lifting ? -1.0 : -0.5;
+        if (mm) {  // phase 2: X_next = alpha X + beta X Yh, Yh = (Y + Y^dagger) / 2 read on the fly
+          const cd* bp = Y + kq * P + col0 + r16;    // Y[k][col]
+          const cd* bt = Y + (col0 + r16) * P + kq;  // Y[col][k]
+          const Tile3 t = tile_product(X + (row0 + r16) * P + kq, [&](int k0) {
+            const cd b0 = bp[k0 * P], b1 = bt[k0];
+            return cd{0.5 * (b0.re + b1.re), 0.5 * (b0.im - b1.im)};
+          });
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int at = (row0 + kq + 4 * r) * P + col0 + r16;
+            const cd x = X[at];
+            Xn[at] = cd{fma(beta, t.re(r), alpha * x.re), fma(beta, t.im(r), alpha * x.im)};
           }
         }
-        const sc_v4f64 acc = sum_chains(accs);
-        double* ydst = reinterpret_cast<double*>(Y) + part;
-        double rp = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = row0 + kq + 4 * r, col = col0 + r16;
-          ydst[(row * P + col) * 2] = acc[r];
-          const double dv = (part == 0 && row == col) ? 1.0 - acc[r] : acc[r];
-          rp = fma(dv, dv, rp);
-        }
-        rp = gsum<64>(rp);
-        if (lane == 0) red[wave] = rp;
+        __syncthreads();
+        const int tmp = xo;  // the new X sits in the third image; the old X image is the next step's target
+        xo = wo;
+        wo = tmp;
+        if (last || !(res == res)) break;
       }
-      __syncthreads();
-      double res = 0.0;
-#pragma unroll
-      for (int w = 0; w < 2 * NTILE; ++w) res += red[w];
-      if (lifting && (res < 0.5 || k >= 40)) lifting = false;
-      const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);  // one more quadratic step squares the error
-      const double alpha = lifting ? 2.0 : 1.5, beta = lifting ? -1.0 : -0.5;
-      if (mm) {  // phase 2: X_next = alpha X + beta X Yh, Yh = (Y + Y^dagger) / 2 read on the fly
-        sc_v4f64 accs[NACC];
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) accs[q] = sc_v4f64{0.0, 0.0, 0.0, 0.0};
-        const cd* ap = X + (row0 + r16) * P + kq;
-        const cd* bp = Y + kq * P + col0 + r16;       // Y[k][col]
-        const cd* bt = Y + (col0 + r16) * P + kq;     // Y[col][k]
-#pragma unroll
-        for (int k0 = 0; k0 < d; k0 += 4) {
-          const cd av = ap[k0], b0 = bp[k0 * P], b1 = bt[k0];
-          const double br = 0.5 * (b0.re + b1.re), bi = 0.5 * (b0.im - b1.im);
-          sc_v4f64& acc = accs[(k0 / 4) % NACC];
-          if (part == 0) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, br, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.im, bi, acc, 0, 0, 0);
-          } else {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, br, acc, 0, 0, 0);
+    } else {
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      const bool mm = wave < 2 * NTILE;  // wave-uniform
+      const int tile = wave >> 1, part = wave & 1;
+      const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
+      const int r16 = lane & 15, kq = lane >> 4;
+      QT_STAMP(26);
+      for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (identical bits in every thread)
+        QT_STAMP_VAL(25, (long long)(k + 1));  // (profile build: steps taken)
+        const cd* X = reinterpret_cast<const cd*>(sm + xo);
+        cd* Y = reinterpret_cast<cd*>(sm + yo);
+        cd* Xn = reinterpret_cast<cd*>(sm + wo);
+        if (mm) {  // phase 1: Y = X X, and this tile's share of res = ||I - Y||_F^2
+          sc_v4f64 accs[NACC];
+  #pragma unroll
+          for (int q = 0; q < NACC; ++q) accs[q] = sc_v4f64{0.0, 0.0, 0.0, 0.0};
+          const cd* ap = X + (row0 + r16) * P + kq;
+          const cd* bp = X + kq * P + col0 + r16;
+  #pragma unroll
+          for (int k0 = 0; k0 < d; k0 += 4) {
+            const cd av = ap[k0], bv = bp[k0 * P];
+            sc_v4f64& acc = accs[(k0 / 4) % NACC];
+            if (part == 0) {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.re, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.im, bv.im, acc, 0, 0, 0);
+            } else {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.im, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.re, acc, 0, 0, 0);
+            }
+          }
+          const sc_v4f64 acc = sum_chains(accs);
+          double* ydst = reinterpret_cast<double*>(Y) + part;
+          double rp = 0.0;
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = row0 + kq + 4 * r, col = col0 + r16;
+            ydst[(row * P + col) * 2] = acc[r];
+            const double dv = (part == 0 && row == col) ? 1.0 - acc[r] : acc[r];
+            rp = fma(dv, dv, rp);
+          }
+          rp = gsum<64>(rp);
+          if (lane == 0) red[wave] = rp;
+        }
+        __syncthreads();
+        double res = 0.0;
+  #pragma unroll
+        for (int w = 0; w < 2 * NTILE; ++w) res += red[w];
+        if (lifting && (res < 0.5 || k >= 40)) lifting = false;
+        const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);  // one more quadratic step squares the error
+        const double alpha = lifting ? 2.0 : 1.5, beta = lifting ? -1.0 : -0.5;
+        if (mm) {  // phase 2: X_next = alpha X + beta X Yh, Yh = (Y + Y^dagger) / 2 read on the fly
+          sc_v4f64 accs[NACC];
+  #pragma unroll
+          for (int q = 0; q < NACC; ++q) accs[q] = sc_v4f64{0.0, 0.0, 0.0, 0.0};
+          const cd* ap = X + (row0 + r16) * P + kq;
+          const cd* bp = Y + kq * P + col0 + r16;       // Y[k][col]
+          const cd* bt = Y + (col0 + r16) * P + kq;     // Y[col][k]
+  #pragma unroll
+          for (int k0 = 0; k0 < d; k0 += 4) {
+            const cd av = ap[k0], b0 = bp[k0 * P], b1 = bt[k0];
+            const double br = 0.5 * (b0.re + b1.re), bi = 0.5 * (b0.im - b1.im);
+            sc_v4f64& acc = accs[(k0 / 4) % NACC];
+            if (part == 0) {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, br, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.im, bi, acc, 0, 0, 0);
+            } else {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bi, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, br, acc, 0, 0, 0);
+            }
+          }
+          const sc_v4f64 acc = sum_chains(accs);
+          const double* xsrc = reinterpret_cast<const double*>(X) + part;
+          double* xdst = reinterpret_cast<double*>(Xn) + part;
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int at = ((row0 + kq + 4 * r) * P + col0 + r16) * 2;
+            xdst[at] = fma(beta, acc[r], alpha * xsrc[at]);
           }
         }
-        const sc_v4f64 acc = sum_chains(accs);
-        const double* xsrc = reinterpret_cast<const double*>(X) + part;
-        double* xdst = reinterpret_cast<double*>(Xn) + part;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int at = ((row0 + kq + 4 * r) * P + col0 + r16) * 2;
-          xdst[at] = fma(beta, acc[r], alpha * xsrc[at]);
-        }
+        __syncthreads();
+        const int tmp = xo;  // the new X sits in the third image; the old X image is the next step's target
+        xo = wo;
+        wo = tmp;
+        if (last || !(res == res)) break;
       }
-      __syncthreads();
-      const int tmp = xo;  // the new X sits in the third image; the old X image is the next step's target
-      xo = wo;
-      wo = tmp;
-      if (last || !(res == res)) break;
     }
     QT_STAMP(27);
     // S = sign(A) sits in the image at xo.  R = (A + A S) / 2 + eps (I - S) / 2

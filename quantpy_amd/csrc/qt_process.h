@@ -208,6 +208,9 @@ struct ProcWG {
     if constexpr (kWgJacobi && kSignClipCP) {
       // eigenvalue clip through the matrix sign function on the FP64 matrix cores (qt_signclip_wg.h): three 16 x 17
       // complex images + reduction scratch inside the `jac` block
+      // (default at d = 16: four real products on two wavefronts.  Three products on ONE wavefront, rotated over the SIMDs of
+      //  co-resident workgroups -- SignClipWG<DC, NE, true> -- measured slower here: CP step 43 -> 49 us per 1024, 4.4 -> 5.1 k
+      //  clocks per iteration step: a d = 16 step is bound by the latency of its one wavefront's chain, not by the matrix pipe)
       using SC = SignClipWG<DC, NE>;
       static_assert(3 * 2 * DC * SC::P + 32 <= kJacDoubles, "the sign-clip images fit the Jacobi block");
       const typename SC::Lds o{0, 2 * DC * SC::P, 4 * DC * SC::P, 6 * DC * SC::P};

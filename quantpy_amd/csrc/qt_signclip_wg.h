@@ -36,7 +36,7 @@ namespace qt {
 
 typedef double sc_v4f64 __attribute__((ext_vector_type(4)));
 
-template <int d, int NT>
+template <int d, int NT, bool THREE_MULT = (d >= 32)>
 struct SignClipWG {
   static_assert(NT == d * d && d % 16 == 0 && NT % 64 == 0, "one thread per matrix element, 16 x 16 MFMA tiles");
   static constexpr int P = d + 1;            // row pitch of the images, in complex elements
@@ -53,7 +53,16 @@ struct SignClipWG {
   // imaginary part): its kernels sit at the 128-register step of four workgroups per CU and the third accumulator tile pushed
   // them over it (k_mle_large_start<4>: 119 VGPRs + 24 AGPRs, three workgroups per CU), and a d = 16 step is not bound by the
   // matrix pipe's throughput in the first place (profiles/round3_phase_timing_cptp.txt).
-  static constexpr bool kThreeMult = d >= 32;
+  static constexpr bool kThreeMult = THREE_MULT;  // (the process kernels of qt_process.h ask for it at d = 16: registers to spare)
+  // Which wavefronts carry the tile products: NTILE consecutive ones starting at duty0().  Where that is fewer than a
+  // quarter of the workgroup (d = 16: one of four), workgroups that share a CU should not all use the same SIMD's matrix
+  // pipe: wavefront w of a workgroup sits on SIMD w mod 4, and the workgroups resident on one CU are those whose indices
+  // differ by multiples of the number of CUs (256 on MI355X: consecutive workgroups go to different XCDs / CUs), so the
+  // starting wavefront rotates with blockIdx / 256.  A heuristic about placement: only the balance depends on it.
+  __device__ __forceinline__ static int duty0() {
+    if constexpr (kThreeMult && NW >= 4 * NTILE) return (int)((blockIdx.x >> 8) % (NW / NTILE)) * NTILE;
+    else return 0;
+  }
   // Independent accumulator chains per product tile.  A dependent v_mfma_f64_16x16x4_f64 costs ~170 clocks of latency
   // against ~16 of issue (profiles/round3_ubench_mfma_f64_warm.txt: one chain per wavefront runs the matrix pipe at 27 of
   // its 46 TFLOP/s), and since round 3 a step of the iteration IS two such chains plus two barriers: the d / 4 k-steps of
@@ -100,8 +109,8 @@ struct SignClipWG {
   // C = A * B.  Ends with a barrier: C is visible to every thread, A and B may be overwritten.
   __device__ static void matmul(const cd* A, const cd* B, cd* C) {
     if constexpr (kThreeMult) {
-      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      if (wave < NTILE) {  // wave-uniform
+      const int wave = (int)(threadIdx.x >> 6) - duty0(), lane = threadIdx.x & 63;
+      if (wave >= 0 && wave < NTILE) {  // wave-uniform
         const int row0 = (wave / TPR) * 16, col0 = (wave % TPR) * 16;
         const int r16 = lane & 15, kq = lane >> 4;
         const cd* bp = B + kq * P + col0 + r16;
@@ -168,8 +177,8 @@ struct SignClipWG {
     // that alone moved nothing at d = 32 -- 127 k clocks per clip as before -- because the ~50 products of a clip are bound by
     // the matrix pipe's throughput, not by barriers; what moved it is fewer MFMAs per product (tile_product above).
     if constexpr (kThreeMult) {
-      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      const bool mm = wave < NTILE;  // wave-uniform: one wavefront per tile (d = 32: one per SIMD)
+      const int wave = (int)(threadIdx.x >> 6) - duty0(), lane = threadIdx.x & 63;
+      const bool mm = wave >= 0 && wave < NTILE;  // wave-uniform: one wavefront per tile (d = 32: one per SIMD)
       const int row0 = (wave / TPR) * 16, col0 = (wave % TPR) * 16;
       const int r16 = lane & 15, kq = lane >> 4;
       QT_STAMP(26);

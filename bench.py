@@ -718,6 +718,14 @@ def main():
         c4["mle"]["hbm_GBps_per_gpu"] = round(bytes5 * b5 / (c4["mle"]["ms_per_launch"] * 1e-3) / 1e9, 2)
         c4["mle"]["mean_nit"] = float(ni5.float().mean().item())
         assert int(st5.sum().item()) == 0
+        if rank == 0:  # the same at eight workgroups per CU (2048 trials): the per-trial rate once the launch is not one round
+            c5b = c5.repeat(8, 1, 1).contiguous()
+            r5b = torch.empty((8 * b5, 32, 32), dtype=torch.complex128, device="cuda")
+            for name, fn in (("lin", lambda: e5.lin_dev(c5b, r5b)), ("mle", lambda: e5.mle_dev(c5b, r5b))):
+                ms_b = timed(fn, 3, e5)
+                c4[name]["batch_2048"] = {"ms_per_launch": round(ms_b, 4), "value": round(8 * b5 / ms_b * 1e3, 1),
+                                          "hbm_GBps": round(bytes5 * 8 * b5 / (ms_b * 1e-3) / 1e9, 2)}
+            del c5b, r5b
         del c5, r5
 
     # ---- bootstrap CIs: strong scaling over ranks (interval.py:598-612) -------------------------------

@@ -59,8 +59,9 @@ struct SignClipWG {
   // pipe: wavefront w of a workgroup sits on SIMD w mod 4, and the workgroups resident on one CU are those whose indices
   // differ by multiples of the number of CUs (256 on MI355X: consecutive workgroups go to different XCDs / CUs), so the
   // starting wavefront rotates with blockIdx / 256.  A heuristic about placement: only the balance depends on it.
+  static constexpr int kDuty = kThreeMult ? NTILE : 2 * NTILE;  // product wavefronts per workgroup
   __device__ __forceinline__ static int duty0() {
-    if constexpr (kThreeMult && NW >= 4 * NTILE) return (int)((blockIdx.x >> 8) % (NW / NTILE)) * NTILE;
+    if constexpr (NW >= 2 * kDuty && NW <= 4) return (int)((blockIdx.x >> 8) % (NW / kDuty)) * kDuty;
     else return 0;
   }
   // Independent accumulator chains per product tile.  A dependent v_mfma_f64_16x16x4_f64 costs ~170 clocks of latency
@@ -120,8 +121,8 @@ struct SignClipWG {
       }
       __syncthreads();
     } else {
-      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      if (wave < 2 * NTILE) {  // wave-uniform
+      const int wave = (int)(threadIdx.x >> 6) - duty0(), lane = threadIdx.x & 63;
+      if (wave >= 0 && wave < 2 * NTILE) {  // wave-uniform
         const int tile = wave >> 1, part = wave & 1;
         const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
         const int r16 = lane & 15, kq = lane >> 4;
@@ -230,8 +231,8 @@ struct SignClipWG {
         if (last || !(res == res)) break;
       }
     } else {
-      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      const bool mm = wave < 2 * NTILE;  // wave-uniform
+      const int wave = (int)(threadIdx.x >> 6) - duty0(), lane = threadIdx.x & 63;
+      const bool mm = wave >= 0 && wave < 2 * NTILE;  // wave-uniform
       const int tile = wave >> 1, part = wave & 1;
       const int row0 = (tile / TPR) * 16, col0 = (tile % TPR) * 16;
       const int r16 = lane & 15, kq = lane >> 4;

@@ -191,8 +191,10 @@ int qt_hs_dist_dim(qt_handle_t* h, int dim, const double* rho, const double* cen
 /* ---- a16: quantpy/tomography/interval.py:610-612 (and :683-685) -------------------------------- */
 /* `dist.sort()`: ascending in-place sort of n float64 values (radix sort on the device; NaN last). */
 int qt_sort_f64(qt_handle_t* h, double* x, long long n, int flags);
-/* `interp1d(np.linspace(0, 1, n), sorted)(conf_levels)`: scipy's linear interpolation on the grid
- * x_i = i / (n - 1); out[n_levels].  A level outside [0, 1] gives NaN (interp1d raises there). */
+/* `interp1d(np.linspace(0, 1, n), sorted)(conf_levels)`: scipy's linear interp1d on real 1-D data is numpy.interp, and
+ * these are its semantics on the grid x_i = i / (n - 1) -- cell x_j <= q < x_(j+1), a level ON a grid point returns
+ * sorted[j] itself, otherwise slope * (q - x_j) + y_j operation by operation; out[n_levels].  A level outside [0, 1]
+ * gives NaN (interp1d raises there). */
 int qt_sorted_quantiles(qt_handle_t* h, const double* sorted, long long n, const double* conf_levels, int n_levels,
                         double* out, int flags);
 

@@ -607,30 +607,42 @@ __global__ void __launch_bounds__(1024) k_sort_small(double* __restrict__ x, int
 // scipy's linear interp1d: hi = searchsorted(x, q) clipped to [1, n-1], lo = hi - 1,
 // y = (y_hi - y_lo) / (x_hi - x_lo) * (q - x_lo) + y_lo, with x_i = i * (1 / (n - 1)) and x_(n-1) = 1 exactly
 // (np.linspace).  q outside [0, 1] gives NaN (interp1d raises; the Python layer checks first).
-// The cell of the grid x_i = i / (n - 1) (np.linspace(0, 1, n): x_(n-1) = 1 exactly) that interp1d evaluates x in:
-// returns lo = hi - 1 with hi = searchsorted(grid, x, 'left') clipped to [1, n - 1]; n >= 2, 0 <= x <= 1.
+// scipy's interp1d(kind='linear') on real 1-D data IS numpy.interp (interp1d._call_linear_np; also in the scipy 1.9.3 the
+// reference pins), so these are numpy.interp's semantics (numpy/_core/src/multiarray/compiled_base.c, arr_interp), on the
+// grid x_i = i / (n - 1) of np.linspace(0, 1, n) (x_(n-1) = 1 exactly): the cell is j with x_j <= x < x_(j+1); a query ON a
+// grid point (or at the right end) returns y_j itself -- rounds 2's kernel took the cell to the LEFT of a grid point and
+// evaluated the line at its right end, one ulp off y_j in ~1 of 3 such cases (found by the property sweep of
+// tests/test_sharded_quantiles.py: levels that are grid points, e.g. 0.5 with n = 2001) -- otherwise
+// slope = (y_(j+1) - y_j) / (x_(j+1) - x_j), y = slope (x - x_j) + y_j, with numpy's retry from the other end if that is NaN.
 struct InterpCell {
-  long long lo;
-  double xl, xh;
+  long long j;   // cell: grid(j) <= x < grid(j + 1), or n - 1 for x = 1
+  double xj, xj1;
+  bool exact;    // x == grid(j) (or j == n - 1): the result is y_j
 };
-__device__ __forceinline__ InterpCell interp_cell(long long n, double x) {
+__device__ __forceinline__ InterpCell interp_cell(long long n, double x) {  // n >= 2, 0 <= x <= 1
   const double step = 1.0 / (double)(n - 1);
   auto grid = [&](long long i) { return i == n - 1 ? 1.0 : (double)i * step; };
-  long long hi = (long long)(x * (double)(n - 1));  // close to the answer; fix up against the actual grid values
-  if (hi > n - 1) hi = n - 1;
-  while (hi > 0 && grid(hi - 1) >= x) --hi;  // smallest i with grid(i) >= x  (searchsorted side='left')
-  while (hi < n - 1 && grid(hi) < x) ++hi;
-  if (hi < 1) hi = 1;
-  return InterpCell{hi - 1, grid(hi - 1), grid(hi)};
+  long long j = (long long)(x * (double)(n - 1));  // close to the answer; fix up against the actual grid values
+  if (j > n - 1) j = n - 1;
+  while (j > 0 && grid(j) > x) --j;
+  while (j < n - 1 && grid(j + 1) <= x) ++j;
+  const double xj = grid(j);
+  return InterpCell{j, xj, j < n - 1 ? grid(j + 1) : 1.0, j == n - 1 || xj == x};
 }
-// scipy's expression, operation by operation: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x - x_lo) + y_lo.
-// No contraction: an fma in place of the last multiply-add changes the last bit (seen at n = 3, where x - x_lo is not a
-// power of two times the slope's scale), and the bootstrap quantiles are compared with interp1d bit for bit.
-__device__ __forceinline__ double interp_value(const InterpCell& c, double x, double yl, double yh) {
+// No contraction: an fma in place of the last multiply-add changes the last bit, and the bootstrap quantiles are compared
+// with interp1d bit for bit.
+__device__ __forceinline__ double interp_value(const InterpCell& c, double x, double yj, double yj1) {
 #pragma clang fp contract(off)
-  const double slope = (yh - yl) / (c.xh - c.xl);
-  const double prod = slope * (x - c.xl);
-  return prod + yl;
+  if (c.exact) return yj;
+  const double slope = (yj1 - yj) / (c.xj1 - c.xj);
+  double res = slope * (x - c.xj);
+  res = res + yj;
+  if (res != res) {  // "If we get nan in one direction, try the other"
+    res = slope * (x - c.xj1);
+    res = res + yj1;
+    if (res != res && yj == yj1) res = yj;
+  }
+  return res;
 }
 
 __global__ void k_interp_sorted(const double* __restrict__ y, long long n, const double* __restrict__ q, int nq,
@@ -647,17 +659,17 @@ __global__ void k_interp_sorted(const double* __restrict__ y, long long n, const
     return;
   }
   const InterpCell c = interp_cell(n, x);
-  out[t] = interp_value(c, x, y[c.lo], y[c.lo + 1]);
+  out[t] = interp_value(c, x, y[c.j], y[c.j < n - 1 ? c.j + 1 : c.j]);
 }
 
 // ---- a16 over several ranks: interval.py:610-612 when the sorted sample is spread over N ranks -------------------------
 // Every rank holds a SORTED shard of the n_total bootstrap distances.  interp1d at a confidence level needs the two order
-// statistics k0 = cell(q).lo and k0 + 1 of the union, not the union: they are found exactly in two small exchanges
+// statistics k0 = cell(q).j and k1 = min(k0 + 1, n - 1) of the union, not the union: they are found exactly in two small exchanges
 // (quantpy_amd/distributed.py) instead of an all-gather of everything and a full sort on every rank --
 //   1. every rank publishes P splitters, shard[j * s] (k_select_splitters);  all-gather [N][P]
 //   2. with cnt_r(v) = number of rank r's splitters <= v, the number of sample values <= v lies between
 //      low(v) = sum_r ((cnt_r - 1) s + 1 | 0) and up(v) = sum_r min(n_r, cnt_r s).  lo = the largest splitter with
-//      up <= k0 (the k0-th value is > lo), hi = the smallest with low >= k0 + 2 (the (k0+1)-th value is <= hi)
+//      up <= k0 (the k0-th value is > lo), hi = the smallest with low >= k1 + 1 (the k1-th value is <= hi)
 //      (k_select_bracket; the same on every rank)
 //   3. every rank publishes how many of its values are <= lo and its values in (lo, hi] -- at most (2 N + 3) s of them
 //      (k_select_window);  all-gather [N][L][2 + W]
@@ -721,9 +733,9 @@ __global__ void __launch_bounds__(256) k_select_bracket(const double* __restrict
   for (int l = 0; l < L; ++l) {
     const double x = q[l];
     if (!(x >= 0.0 && x <= 1.0) || n_total < 2) continue;
-    const long long k0 = interp_cell(n_total, x).lo;
+    const long long k0 = interp_cell(n_total, x).j, k1 = k0 < n_total - 1 ? k0 + 1 : k0;
     if (up <= k0) atomicMax(lo_key + l, kv);
-    if (low >= k0 + 2) atomicMin(hi_key + l, kv);
+    if (low >= k1 + 1) atomicMin(hi_key + l, kv);
   }
 }
 
@@ -787,13 +799,14 @@ __global__ void __launch_bounds__(1024) k_select_finish(const double* __restrict
     for (int e = threadIdx.x; e < cnt && o + e < cap; e += blockDim.x) cand[o + e] = w[e];
   }
   __syncthreads();
-  long long k0 = 0;
-  InterpCell cell{0, 0.0, 1.0};
+  long long k0 = 0, k1 = 0;
+  InterpCell cell{0, 0.0, 1.0, true};
   if (n_total >= 2) {
     cell = interp_cell(n_total, x);
-    k0 = cell.lo;
+    k0 = cell.j;
+    k1 = k0 < n_total - 1 ? k0 + 1 : k0;
   }
-  const long long t0 = k0 - s_below, t1 = t0 + 1;
+  const long long t0 = k0 - s_below, t1 = k1 - s_below;
   for (int e = threadIdx.x; e < tot; e += blockDim.x) {
     const unsigned long long kv = sort_key(cand[e]);
     long long lt = 0, le = 0;
@@ -807,7 +820,7 @@ __global__ void __launch_bounds__(1024) k_select_finish(const double* __restrict
     if (lt <= t1 && t1 < le) picked[1] = cand[e];
   }
   __syncthreads();
-  if (threadIdx.x == 0) out[l] = n_total == 1 ? picked[0] : interp_value(cell, x, picked[0], picked[1]);
+  if (threadIdx.x == 0) out[l] = interp_value(cell, x, picked[0], picked[1]);  // (n_total = 1: the cell is exact)
 }
 
 // ---- f2: stats.py:21-47 l2_first_moment / l2_second_moment over a batch of trials (MomentInterval, interval.py:59-110) --

@@ -137,20 +137,36 @@ def _sort_keys(a):
 
 
 def interp_cell(n, q):
-    """The cell of np.linspace(0, 1, n) that scipy's interp1d evaluates q in: (lo, x_lo, x_hi) with lo + 1 =
-    searchsorted(grid, q, 'left') clipped to [1, n - 1] (the same walk as the device's interp_cell, qt_ops.h)."""
+    """The cell of np.linspace(0, 1, n) that numpy.interp -- which is what scipy's interp1d(kind='linear') calls for real
+    1-D data -- evaluates q in: (j, x_j, x_(j+1), exact) with x_j <= q < x_(j+1) (j = n - 1 for q = 1); `exact`: q is the
+    grid point x_j, the result is y_j itself.  The same walk as the device's interp_cell (csrc/qt_ops.h)."""
     step = 1.0 / (n - 1)
 
     def grid(i):
         return 1.0 if i == n - 1 else i * step
 
-    hi = min(int(q * (n - 1)), n - 1)
-    while hi > 0 and grid(hi - 1) >= q:
-        hi -= 1
-    while hi < n - 1 and grid(hi) < q:
-        hi += 1
-    hi = max(hi, 1)
-    return hi - 1, grid(hi - 1), grid(hi)
+    j = min(int(q * (n - 1)), n - 1)
+    while j > 0 and grid(j) > q:
+        j -= 1
+    while j < n - 1 and grid(j + 1) <= q:
+        j += 1
+    xj = grid(j)
+    return j, xj, (grid(j + 1) if j < n - 1 else 1.0), (j == n - 1 or xj == q)
+
+
+def interp_value(cell, q, yj, yj1):
+    """numpy.interp's arithmetic for one query (compiled_base.c, arr_interp), operation by operation."""
+    _, xj, xj1, exact = cell
+    if exact:
+        return yj
+    with np.errstate(invalid="ignore"):
+        slope = (yj1 - yj) / (xj1 - xj)
+        res = slope * (q - xj) + yj
+        if np.isnan(res):
+            res = slope * (q - xj1) + yj1
+            if np.isnan(res) and yj == yj1:
+                res = yj
+    return res
 
 
 def selection_plan(n_total, world_size, n_levels):
@@ -235,8 +251,8 @@ class ShardedSample:
             return np.full(len(levels), srt[0])
         out = np.empty(len(levels))
         for t, q in enumerate(levels):
-            lo, xl, xh = interp_cell(n, float(q))
-            out[t] = (srt[lo + 1] - srt[lo]) / (xh - xl) * (q - xl) + srt[lo]
+            cell = interp_cell(n, float(q))
+            out[t] = interp_value(cell, q, srt[cell[0]], srt[min(cell[0] + 1, n - 1)])
         return out
 
     def quantiles(self, levels):
@@ -287,48 +303,87 @@ class ShardedSample:
 
     # -- the same four steps in NumPy (host-resident shards: the reference's own distances, the gloo tests) ---------------
     def _select_host(self, levels, stride, n_split, width):
-        n, nr = self.n_total, self.world
-        keys = _sort_keys(self.local)
-        pad = np.uint64(0xFFFFFFFFFFFFFFFF)
-        spl = np.full(n_split, pad, dtype=np.uint64)
-        take = keys[::stride]
-        spl[: len(take)] = take
+        spl = host_splitters(self.local, stride, n_split)
         all_spl = allgather_equal(spl.view(np.int64)).view(np.uint64)  # (N, P), bit patterns
-        valid = [int(-(-self.sizes[r] // stride)) for r in range(nr)]
-        cand = np.concatenate([all_spl[r, : valid[r]] for r in range(nr)])
-        up = np.zeros(len(cand), dtype=np.int64)
-        low = np.zeros(len(cand), dtype=np.int64)
-        for r in range(nr):
-            cnt = np.searchsorted(all_spl[r, : valid[r]], cand, side="right").astype(np.int64)
-            up += np.minimum(self.sizes[r], cnt * stride)
-            low += np.where(cnt > 0, (cnt - 1) * stride + 1, 0)
-        win = np.zeros((levels.size, 2 + width))
-        cells = []
-        for t, qv in enumerate(levels):
-            k0 = interp_cell(n, float(qv))[0] if n >= 2 else 0
-            cells.append(k0)
-            sel_lo = cand[up <= k0]
-            sel_hi = cand[low >= k0 + 2] if n >= 2 else cand[:0]
-            below = int(np.searchsorted(keys, sel_lo.max(), side="right")) if sel_lo.size else 0
-            upto = int(np.searchsorted(keys, sel_hi.min(), side="right")) if sel_hi.size else len(keys)
-            w = upto - below
-            win[t, 0], win[t, 1] = below, w
-            win[t, 2: 2 + min(w, width)] = self.local[below: below + min(w, width)]
+        lo, hi = host_bracket(all_spl, self.sizes, stride, self.n_total, levels)
+        win = host_window(self.local, lo, hi, width)
         all_win = allgather_equal(win)  # (N, L, 2 + W)
-        if (all_win[:, :, 1] > width).any():
-            return None
-        out = np.empty(levels.size)
+        return host_finish(all_win, self.n_total, levels, width)
+
+
+# The four local steps of the selection as plain functions of NumPy arrays (the kernels of csrc/qt_ops.h restated; the
+# product's path for host-resident shards and the checker of the kernels): with the all-gathers replaced by np.stack they
+# run N simulated ranks in one process (tests/test_sharded_quantiles.py sweeps random samples that way).
+_KEY_NONE_LO, _KEY_NONE_HI = np.uint64(0), np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def host_splitters(local_sorted, stride, n_split):
+    """Radix-sort keys of local_sorted[::stride], padded behind everything to n_split entries."""
+    spl = np.full(n_split, _KEY_NONE_HI, dtype=np.uint64)
+    take = _sort_keys(local_sorted)[::stride]
+    spl[: len(take)] = take
+    return spl
+
+
+def host_bracket(all_spl, sizes, stride, n_total, levels):
+    """Per level the tightest splitter pair (lo, hi] that provably holds the order statistics k0 = cell(q) and k1 of the union
+    = min(k0 + 1, n - 1) (keys; 0 / ~0 = none): lo = largest splitter with sum_r min(n_r, cnt_r s) <= k0, hi = smallest with
+    sum_r ((cnt_r - 1) s + 1) >= k1 + 1, cnt_r(v) = rank r's splitters <= v."""
+    nr = len(sizes)
+    valid = [int(-(-int(sizes[r]) // stride)) for r in range(nr)]
+    cand = np.concatenate([all_spl[r, : valid[r]] for r in range(nr)]) if sum(valid) else np.empty(0, dtype=np.uint64)
+    up = np.zeros(len(cand), dtype=np.int64)
+    low = np.zeros(len(cand), dtype=np.int64)
+    for r in range(nr):
+        cnt = np.searchsorted(all_spl[r, : valid[r]], cand, side="right").astype(np.int64)
+        up += np.minimum(int(sizes[r]), cnt * stride)
+        low += np.where(cnt > 0, (cnt - 1) * stride + 1, 0)
+    lo = np.full(len(levels), _KEY_NONE_LO, dtype=np.uint64)
+    hi = np.full(len(levels), _KEY_NONE_HI, dtype=np.uint64)
+    if n_total >= 2:
         for t, qv in enumerate(levels):
-            below = int(all_win[:, t, 0].sum())
-            union = np.sort(np.concatenate([all_win[r, t, 2: 2 + int(all_win[r, t, 1])] for r in range(nr)]), kind="stable")
-            k0 = cells[t]
-            if n == 1:
-                out[t] = union[k0 - below]
-                continue
-            _, xl, xh = interp_cell(n, float(qv))
-            yl, yh = union[k0 - below], union[k0 + 1 - below]
-            out[t] = (yh - yl) / (xh - xl) * (qv - xl) + yl
-        return out
+            k0 = interp_cell(n_total, float(qv))[0]
+            k1 = min(k0 + 1, n_total - 1)
+            sel_lo, sel_hi = cand[up <= k0], cand[low >= k1 + 1]
+            if sel_lo.size:
+                lo[t] = sel_lo.max()
+            if sel_hi.size:
+                hi[t] = sel_hi.min()
+    return lo, hi
+
+
+def host_window(local_sorted, lo, hi, width):
+    """win[l] = [#values <= lo, w = #values in (lo, hi], the first min(w, width) of them]."""
+    keys = _sort_keys(local_sorted)
+    win = np.zeros((len(lo), 2 + width))
+    for t in range(len(lo)):
+        below = 0 if lo[t] == _KEY_NONE_LO else int(np.searchsorted(keys, lo[t], side="right"))
+        upto = len(keys) if hi[t] == _KEY_NONE_HI else int(np.searchsorted(keys, hi[t], side="right"))
+        w = upto - below
+        win[t, 0], win[t, 1] = below, w
+        win[t, 2: 2 + min(w, width)] = local_sorted[below: below + min(w, width)]
+    return win
+
+
+def host_finish(all_win, n_total, levels, width):
+    """interp1d(linspace(0, 1, n_total), sorted union)(levels) from the gathered windows, or None when a window was
+    clipped (w > width: heavy ties -- the caller gathers the sorted shards instead)."""
+    if (all_win[:, :, 1] > width).any():
+        return None
+    nr = all_win.shape[0]
+    out = np.empty(len(levels))
+    for t, qv in enumerate(levels):
+        below = int(all_win[:, t, 0].sum())
+        union = np.concatenate([all_win[r, t, 2: 2 + int(all_win[r, t, 1])] for r in range(nr)])
+        union = union[np.argsort(_sort_keys(union), kind="stable")]
+        if n_total == 1:
+            out[t] = union[0 - below]
+            continue
+        cell = interp_cell(n_total, float(qv))
+        k0 = cell[0]
+        k1 = min(k0 + 1, n_total - 1)
+        out[t] = interp_value(cell, qv, union[k0 - below], union[k1 - below])
+    return out
 
 
 def sharded_map(items, fn):

@@ -371,3 +371,52 @@ def test_the_collectives_of_the_sharded_path_on_a_one_rank_rccl_group(tmp_path):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     res = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "rccl ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+def test_quantile_kernels_on_grid_points_and_random_samples(qp):
+    """numpy.interp's semantics on the device (what interp1d calls for real 1-D data): levels that ARE grid points return the
+    order statistic itself (round 2's kernel was one ulp off in a third of such cases: 0.5 with n = 2001); and a random
+    sweep of the selection kernels (sizes, rank counts, tie structures, levels on and between grid points) against
+    np.sort + interp1d -- bit for bit whenever the kernels do not raise their overflow flag."""
+    import torch
+    from scipy.interpolate import interp1d
+
+    from quantpy_amd import distributed as qd
+
+    eng = qp.get_engine(1)
+    rng = np.random.default_rng(77)
+    for n in (2, 5, 102, 2001, 8192, 20001):
+        y = rng.gamma(2.0, 0.01, n)
+        grid = np.linspace(0, 1, n)
+        qs = np.unique(np.clip(np.concatenate([grid[:: max(1, n // 400)], np.nextafter(grid[:: max(1, n // 300)], 2),
+                                               np.nextafter(grid[:: max(1, n // 300)], -1), [0.0, 0.5, 1.0]]), 0, 1))
+        srt, got = eng.sort_quantiles(y, qs)
+        assert np.array_equal(srt, np.sort(y)) and np.array_equal(got, interp1d(grid, np.sort(y))(qs)), n
+    declined = 0
+    for case in range(160):
+        n_ranks, n = int(rng.integers(1, 10)), int(rng.integers(1, 4000))
+        kind = ("cont", "r3", "r1", "zeros", "nan", "const")[case % 6]
+        x = rng.gamma(2.0, 0.01, n)
+        if kind == "r3":
+            x = np.round(x, 3)
+        elif kind == "r1":
+            x = np.round(x, 1)
+        elif kind == "zeros":
+            x[rng.random(n) < 0.3] = 0.0
+        elif kind == "nan":
+            x[rng.integers(0, n)] = np.nan
+        elif kind == "const":
+            x[:] = 0.25
+        grid = np.linspace(0, 1, n) if n > 1 else np.array([0.0])
+        levels = np.concatenate([rng.random(3), grid[rng.integers(0, len(grid), 2)], [0.0, 1.0]])
+        plan = qd.selection_plan(n, n_ranks, len(levels)) if case % 2 else None
+        if plan is None:
+            n_max = -(-n // n_ranks)
+            stride = int(rng.integers(1, max(2, n_max // 2 + 1)))
+            plan = (stride, -(-n_max // stride), int(rng.integers(1, min(3 * n_max + 2, 1500))))
+        got, flag, _ = simulated_rank_quantiles(eng, x, levels, n_ranks, plan)
+        if flag:
+            declined += 1
+            continue
+        assert np.array_equal(got, reference_quantiles(x, levels), equal_nan=True), (case, n_ranks, n, kind, plan)
+    assert declined < 100

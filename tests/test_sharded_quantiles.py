@@ -50,14 +50,23 @@ def test_single_rank_is_sort_plus_interp1d():
     for name, (x, lv) in sample_cases().items():
         got = ShardedSample(x.copy(), len(x)).quantiles(lv)
         assert np.array_equal(got, reference_quantiles(x, lv), equal_nan=True), name
-    # the cell walk equals searchsorted on the actual grid, also where q * (n - 1) rounds across a grid point
-    for n in (2, 3, 7, 1000, 2000, 2097152):
+    # the cell walk is numpy.interp's (x_j <= q < x_(j+1); what interp1d calls for real 1-D data) on the actual grid, also
+    # where q * (n - 1) rounds across a grid point; queries ON grid points return y_j itself
+    for n in (2, 3, 7, 102, 1000, 2000, 2001, 2097152):
         grid = np.linspace(0, 1, n)
-        qs = np.concatenate([grid[:: max(1, n // 257)], np.nextafter(grid[:: max(1, n // 263)], 2), [0.0, 1.0, 0.3, 0.999999]])
+        qs = np.concatenate([grid[:: max(1, n // 257)], np.nextafter(grid[:: max(1, n // 263)], 2),
+                             np.nextafter(grid[:: max(1, n // 251)], -1), [0.0, 1.0, 0.3, 0.5, 0.999999]])
         for q in qs[(qs >= 0) & (qs <= 1)]:
-            hi = min(max(np.searchsorted(grid, q, "left"), 1), n - 1)
-            lo, xl, xh = interp_cell(n, float(q))
-            assert (lo, xl, xh) == (hi - 1, grid[hi - 1], grid[hi]), (n, q)
+            j = min(max(int(np.searchsorted(grid, q, "right")) - 1, 0), n - 1)
+            cj, xj, xj1, exact = interp_cell(n, float(q))
+            assert (cj, xj, exact) == (j, grid[j], bool(j == n - 1 or grid[j] == q)), (n, q)
+            assert xj1 == (grid[j + 1] if j < n - 1 else 1.0)
+    rng = np.random.default_rng(3)
+    for n in (2, 5, 102, 2001):  # every grid point and its neighbours against interp1d itself
+        y = np.sort(rng.gamma(2.0, 0.01, n))
+        grid = np.linspace(0, 1, n)
+        qs = np.unique(np.clip(np.concatenate([grid, np.nextafter(grid, 2), np.nextafter(grid, -1)]), 0, 1))
+        assert np.array_equal(ShardedSample(y.copy(), n).quantiles(qs), interp1d(grid, y)(qs))
 
 
 def test_selection_plan_moves_less_than_the_sample():
@@ -118,3 +127,61 @@ def test_sharded_quantiles_equal_sort_plus_interp1d_gloo(tmp_path, world_size):
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     for r in range(world_size):
         assert f"rank {r}/{world_size} ok" in res.stdout
+
+
+def simulate_ranks_host(x, levels, n_ranks, plan):
+    """The four selection steps with N ranks played in one process (np.stack in place of the all-gathers)."""
+    from quantpy_amd import distributed as qd
+
+    stride, n_split, width = plan
+    bounds = [qd.shard_bounds(len(x), r, n_ranks) for r in range(n_ranks)]
+    shards = [np.sort(x[lo:hi]) for lo, hi in bounds]
+    sizes = np.array([hi - lo for lo, hi in bounds], dtype=np.int64)
+    all_spl = np.stack([qd.host_splitters(s, stride, n_split) for s in shards])
+    lo, hi = qd.host_bracket(all_spl, sizes, stride, len(x), levels)
+    all_win = np.stack([qd.host_window(s, lo, hi, width) for s in shards])
+    return qd.host_finish(all_win, len(x), levels, width), (lo, hi, all_win)
+
+
+def test_selection_steps_on_random_samples_in_process():
+    """Property sweep of the distributed selection (many sizes, rank counts, tie structures, levels on and between grid
+    points): whenever it returns a value it is np.sort + interp1d's, bit for bit; it may only decline (None) when a window
+    really overflowed; and with the product's own plan and tie-free data it never declines."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from quantpy_amd import distributed as qd
+
+    @settings(max_examples=400, deadline=None)
+    @given(st.integers(1, 9), st.integers(1, 1500), st.integers(0, 2**31 - 1), st.sampled_from(["cont", "r3", "r1", "zeros", "nan", "const"]),
+           st.integers(1, 6), st.booleans())
+    def prop(n_ranks, n, seed, kind, n_levels, own_plan):
+        rng = np.random.default_rng(seed)
+        x = rng.gamma(2.0, 0.01, n)
+        if kind == "r3":
+            x = np.round(x, 3)
+        elif kind == "r1":
+            x = np.round(x, 1)
+        elif kind == "zeros":
+            x[rng.random(n) < 0.3] = 0.0
+        elif kind == "nan":
+            x[rng.integers(0, n)] = np.nan
+        elif kind == "const":
+            x[:] = 0.25
+        grid = np.linspace(0, 1, n) if n > 1 else np.array([0.0])
+        levels = np.concatenate([rng.random(n_levels), grid[rng.integers(0, len(grid), 2)], [0.0, 1.0]])[: n_levels + 2]
+        plan = qd.selection_plan(n, n_ranks, len(levels)) if own_plan else None
+        if plan is None:
+            n_max = -(-n // n_ranks)
+            stride = int(rng.integers(1, max(2, n_max // 2 + 1)))
+            plan = (stride, -(-n_max // stride), int(rng.integers(1, 3 * n_max + 2)))
+        got, (lo, hi, all_win) = simulate_ranks_host(x, levels, n_ranks, plan)
+        want = reference_quantiles(x, levels)
+        if got is None:
+            assert (all_win[:, :, 1] > plan[2]).any()
+        else:
+            assert np.array_equal(got, want, equal_nan=True), (n_ranks, n, kind, plan, got, want)
+        if own_plan and kind == "cont" and qd.selection_plan(n, n_ranks, len(levels)) is not None:
+            assert got is not None  # the (2 N + 3) stride bound holds for tie-free data
+
+    prop()

@@ -136,3 +136,21 @@ def test_process_coverage_table_of_the_verification_notebook(qp):
         assert np.allclose(qp.MomentInterval(tmg)(levels)[0], radii[-1], rtol=1e-12)  # tmg holds the last resample
     print("\n".join(["process coverage (z vs the notebook's value in brackets):"] + report))
     assert (np.concatenate(zs) <= 3).mean() >= 0.85
+
+
+@pytest.mark.parametrize("s,k,rows,batch", [(5, 3, 7, 9), (1, 6, 4, 5), (35, 31, 10, 6), (81, 16, 256, 3), (144, 4, 256, 10), (2, 512, 3, 2)])
+def test_moment_kernel_on_arbitrary_shapes(qp, oracle, s, k, rows, batch):
+    """qt_moment_batch does not depend on the handle's POVM: any (S, K) and any weight operator, settings with unequal
+    shots included -- odd sizes, the four-trials-per-workgroup kernel (S K <= 1024), the one-trial kernel above it (1085, 1296
+    rows), process-shaped data (144 x 4) -- against the reference's einsums (oracle.l2_moments)."""
+    rng = np.random.default_rng(s * 1000 + k)
+    inv = rng.standard_normal((rows, s * k)) * 0.1
+    ns = rng.integers(20, 60, s)
+    ns[0] = 37
+    counts = np.stack([np.stack([rng.multinomial(int(ns[i]), rng.dirichlet(np.ones(k))) for i in range(s)]) for _ in range(batch)])
+    eng = qp.get_engine(1)
+    mean, var = eng.moments(counts, ns, inv)
+    for b in range(batch):
+        m0, v0 = oracle.l2_moments(counts[b] / ns[:, None], float(ns[0]), inv)
+        assert abs(mean[b] - m0) <= 1e-12 * abs(m0), (b, mean[b], m0)
+        assert abs(var[b] - v0) <= 1e-9 * abs(v0) + 1e-14 * m0 * m0, (b, var[b], v0)

@@ -63,6 +63,12 @@ def test_fused_distance_equals_two_pass(qp, oracle, n, shots, batch):
             assert got[0] == 0.0  # the centre's own counts: hs_dst returns an exact 0 below 1e-15
         for i in range(min(3, len(counts_i))):  # the oracle's hs_dst on the two-pass matrices (geometry.py:16-20)
             assert abs(got[i] - oracle.hs_dst(two_pass_rho[i], centre)) < 1e-13
+    # hs_dst is defined for any pair of matrices (geometry.py:16: sqrt(|Tr((A - B)^2)|) / sqrt(2), no conjugation): a centre
+    # that is not Hermitian goes through the same formula
+    odd = centre + 0.05 * (rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))
+    got_odd = eng.mle_dist(counts[:3], odd)
+    for i in range(3):
+        assert abs(got_odd[i] - oracle.hs_dst(eng.mle(counts[i]), odd)) < 1e-13
     for physical in (True, False):
         lin_rho = eng.lin(counts, physical=physical)
         assert np.abs(eng.lin_dist(counts, centre, physical=physical) - eng.hs_dist(lin_rho, centre)).max() < 1e-15

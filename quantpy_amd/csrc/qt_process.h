@@ -31,11 +31,12 @@ struct ProcessState {
   void* vs_pinv = nullptr;   // [D][D] complex: left inverse of V_S = [vec rho_s]
   void* vp_pinv = nullptr;   // [D][M] complex: left inverse of V_P = [vec E_m] (index e d + b)
   void* vp_pinvT = nullptr;  // [M][D] complex: its transpose, the right-hand operand of T = F V_P^+^T
+  void* vp_perm = nullptr;   // [4][M][32] real: the same, columns grouped per workgroup of k_lifp64 (M % 4 == 0 only)
   bool factored = false;
   size_t cap_rows = 0;
   void release() {
     factored = false;
-    for (void** p : {&lifp, &pinvT, &pinvR, &emats, &in_states, &aug, &pinv, &vs_pinv, &vp_pinv, &vp_pinvT}) {
+    for (void** p : {&lifp, &pinvT, &pinvR, &emats, &in_states, &aug, &pinv, &vs_pinv, &vp_pinv, &vp_pinvT, &vp_perm}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }

@@ -82,39 +82,42 @@ struct Proc64 {
     }
   };
 
-  // tile(s) (row0, col0 [, col0 + 16]) of A B into registers (c[0..3]: first tile, c[4..7]: second); no barrier inside
+  // tile(s) (row0, col0 [, col0 + 16]) of A B into registers (c[0..3]: first tile, c[4..7]: second); no barrier inside.
+  // THREE real products per complex tile (round 3, as SignClipWG::tile_product at d = 32): P1 = Ar Br, P2 = Ai Bi,
+  // P3 = (Ar + Ai)(Br + Bi), C = (P1 - P2) + i (P3 - P1 - P2) -- the step is bound by the throughput of the FP64 matrix
+  // pipe (448 v_mfma_f64_16x16x4_f64 per SIMD and step with four products, 336 with three), and the three (six with two
+  // tiles) accumulator chains are independent.
   __device__ __forceinline__ static void tiles(const cd* A, const cd* B, int row0, int col0, bool two, int r16, int kq,
                                                cd (&c)[EPT]) {
-    sc_v4f64 re0 = {0.0, 0.0, 0.0, 0.0}, im0 = re0, re1 = re0, im1 = re0;
+    const sc_v4f64 z = {0.0, 0.0, 0.0, 0.0};
+    sc_v4f64 p1a = z, p2a = z, p3a = z, p1b = z, p2b = z, p3b = z;
     const cd* ap = A + (row0 + r16) * P + kq;
     const cd* bp = B + kq * P + col0 + r16;
     if (two) {  // wave-uniform
 #pragma unroll 4
       for (int k0 = 0; k0 < DC; k0 += 4) {
         const cd a = ap[k0], b0 = bp[k0 * P], b1 = bp[k0 * P + 16];
-        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, re0, 0, 0, 0);
-        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.im, im0, 0, 0, 0);
-        re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.re, re1, 0, 0, 0);
-        im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.im, im1, 0, 0, 0);
-        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b0.im, re0, 0, 0, 0);
-        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.re, im0, 0, 0, 0);
-        re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b1.im, re1, 0, 0, 0);
-        im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b1.re, im1, 0, 0, 0);
+        const double as = a.re + a.im;
+        p1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, p1a, 0, 0, 0);
+        p1b = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.re, p1b, 0, 0, 0);
+        p2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.im, p2a, 0, 0, 0);
+        p2b = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b1.im, p2b, 0, 0, 0);
+        p3a = __builtin_amdgcn_mfma_f64_16x16x4f64(as, b0.re + b0.im, p3a, 0, 0, 0);
+        p3b = __builtin_amdgcn_mfma_f64_16x16x4f64(as, b1.re + b1.im, p3b, 0, 0, 0);
       }
     } else {
 #pragma unroll 4
       for (int k0 = 0; k0 < DC; k0 += 4) {
         const cd a = ap[k0], b0 = bp[k0 * P];
-        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, re0, 0, 0, 0);
-        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.im, im0, 0, 0, 0);
-        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b0.im, re0, 0, 0, 0);
-        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.re, im0, 0, 0, 0);
+        p1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, p1a, 0, 0, 0);
+        p2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.im, p2a, 0, 0, 0);
+        p3a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, b0.re + b0.im, p3a, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      c[r] = cd{re0[r], im0[r]};
-      c[4 + r] = cd{re1[r], im1[r]};
+      c[r] = cd{p1a[r] - p2a[r], p3a[r] - p1a[r] - p2a[r]};
+      c[4 + r] = cd{p1b[r] - p2b[r], p3b[r] - p1b[r] - p2b[r]};
     }
   }
   // the Hermitian products: this wavefront's share of the upper tiles
@@ -139,6 +142,43 @@ struct Proc64 {
         if (col0 != wk.row0) D[j * P + i] = cd{c[4 * t + r].re, -c[4 * t + r].im};
       }
     }
+  }
+  // The same for a product that is Hermitian up to rounding (Y = X X, Z = Y Y): a tile ON the diagonal is replaced by its
+  // Hermitian part -- inside the wavefront that computed it: raw store, transposed read, second store; LDS serves one
+  // wavefront's accesses in program order -- so the image is exactly Hermitian when the barrier after it opens, and c[]
+  // holds what was stored.  Returns this wavefront's share of sum |delta_ij - D_ij|^2 over the WHOLE matrix (elements of
+  // an off-diagonal tile count twice: their mirror images).
+  __device__ __forceinline__ static double store_hermitian(cd* D, const Work& wk, cd (&c)[EPT]) {
+    double rp = 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && !wk.two) break;
+      const int col0 = wk.col0 + 16 * t;
+      const bool diag = col0 == wk.row0;  // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = wk.row0 + wk.kq + 4 * r, j = col0 + wk.r16;
+        D[i * P + j] = c[4 * t + r];
+        if (!diag) D[j * P + i] = cd{c[4 * t + r].re, -c[4 * t + r].im};
+      }
+      if (diag) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = wk.row0 + wk.kq + 4 * r, j = col0 + wk.r16;
+          const cd ct = D[j * P + i];
+          c[4 * t + r] = cd{0.5 * (c[4 * t + r].re + ct.re), 0.5 * (c[4 * t + r].im - ct.im)};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D[(wk.row0 + wk.kq + 4 * r) * P + col0 + wk.r16] = c[4 * t + r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = wk.row0 + wk.kq + 4 * r, j = col0 + wk.r16;
+        const double dr = (i == j ? 1.0 : 0.0) - c[4 * t + r].re, di = c[4 * t + r].im;
+        rp += (diag ? 1.0 : 2.0) * (dr * dr + di * di);
+      }
+    }
+    return rp;
   }
 
   // Hermitian completion from the lower triangle (LAPACK zheevd, uplo = 'L': what numpy.linalg.eigh reads)
@@ -233,34 +273,49 @@ struct Proc64 {
     bool lifting = true;
     int ns_left = 12, steps = 0;
     const Work wk(m.tid);  // (derived from the caller's re-derived thread index: see dykstra)
-    for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (wsum returns identical bits)
+    const int wave = m.tid >> 6;
+    // A step (round 3: three barriers where there were six, and a lifting polynomial of degree 5).
+    //   phase 1  Y = X X on the upper tiles, mirrored (store_hermitian); res = ||I - Y||_F^2 out of the accumulators.
+    //   lifting  x <- x (3 - 3.25 x^2 + 1.25 x^4):  Z = Y Y (Hermitian again: upper tiles), W' = -3.25 Y + 1.25 Z written over Y
+    //            by the wavefronts that own the tiles, X <- 3 X + X W'.
+    //   Newton-Schulz  X <- 1.5 X - 0.5 X Y, finished in the accumulators of the product.
+    // The cubic 1.9 x - 0.9 x^3 (round 2; qt_signclip_wg.h explains why not 2 x - x^3 at d = 64) grows an unlifted
+    // eigenvalue by 1.9 for 3 + 4 tile products per SIMD (a Hermitian product occupies the busiest matrix pipe for 3 tiles, a
+    // general one for 4); the quintic by 3.0 for 3 + 3 + 4: 0.110 against 0.092 e-foldings per tile product.  It is the odd
+    // quintic with p(1) = 1, p'(1) = -1/2 (lifted eigenvalues settle on 1 geometrically, so res ends up measuring the
+    // stragglers only) and slope 3 at 0; slope 3.2 is where the invariant interval [0, 1.26] is lost
+    // (scripts/sign_schedule_model.py: same clip to 1e-14, same Dykstra counts, 10 % fewer tile products on the fixtures'
+    // five clips; the steps are bound by the matrix pipe's throughput, profiles/README.md).
+    for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (identical bits in every thread)
       cd pr[EPT];
       tile_product(X, X, wk, pr);
-      store_tiles(Y, wk, pr);  // (image 1 is idle: the last product ended behind a barrier)
+      double rs = store_hermitian(Y, wk, pr);  // (image 1 is idle: the last product ended behind a barrier)
+      rs = gsum<64>(rs);
+      if ((m.tid & 63) == 0) red[wave] = rs;
       __syncthreads();
-      cd y[EPT];
-      double rs = 0.0;
+      double res = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) res += red[w];
+      if (lifting && (res < 0.5 || k >= 24)) lifting = false;  // (3^24 = 2.8e11: what is still unlifted then is below 1e-11 ||A||)
+      const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);
+      double alpha = 1.5, beta = -0.5;
+      if (lifting) {  // uniform
+        cd pz[EPT];
+        tile_product(Y, Y, wk, pz);
+        __syncthreads();  // every wavefront has read Y
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) pz[r] = cd{fma(1.25, pz[r].re, -3.25 * pr[r].re), fma(1.25, pz[r].im, -3.25 * pr[r].im)};
+        (void)store_hermitian(Y, wk, pz);  // W' (its diagonal tiles symmetrised like Y's)
+        __syncthreads();
+        alpha = 3.0, beta = 1.0;
+      }
+      own_product(X, Y, m, pr);
 #pragma unroll
       for (int r = 0; r < EPT; ++r) {
-        const cd y0 = Y[e[r]], yt = Y[et[r]];
-        y[r] = cd{0.5 * (y0.re + yt.re), 0.5 * (y0.im - yt.im)};  // Hermitian part (a no-op off the diagonal tiles)
-        const double dr = (e[r] == et[r] ? 1.0 : 0.0) - y[r].re;
-        rs += dr * dr + y[r].im * y[r].im;
+        const cd x = X[e[r]];
+        pr[r] = cd{fma(beta, pr[r].re, alpha * x.re), fma(beta, pr[r].im, alpha * x.im)};
       }
-      const double res = wsum(red, rs);  // (its first barrier also ends the reads of Y)
-      if (lifting && (res < 0.5 || k >= 40)) lifting = false;
-      const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);
-      // Lifting with 1.9 x - 0.9 x^3 instead of qt_signclip_wg.h's 2 x - x^3: that one has slope -1 at x = 1, so the
-      // eigenvalues already lifted keep oscillating around 1 with an amplitude that decays only algebraically; at
-      // d = 64 their sum keeps res above 1/2 long after the last small eigenvalue has arrived (27 steps on the n = 3
-      // fixtures, 30 on a +-1 spectrum).  Slope -0.8 damps the oscillation geometrically for 5 % less growth per step:
-      // 19 steps and 9, same accuracy (NumPy model of this loop; at d <= 32 the original pair is as good or better).
-      const double alpha = lifting ? 1.9 : 1.5, beta = lifting ? -0.9 : -0.5;
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) Y[e[r]] = cd{fma(beta, y[r].re, e[r] == et[r] ? alpha : 0.0), beta * y[r].im};  // W
-      __syncthreads();
-      own_product(X, Y, m, pr);
-      __syncthreads();  // every wavefront has read X and W
+      __syncthreads();  // every wavefront has read X and Y
 #pragma unroll
       for (int r = 0; r < EPT; ++r) X[e[r]] = pr[r];
       __syncthreads();
@@ -495,6 +550,117 @@ __global__ void __launch_bounds__(256) k_lifp_kron_finish(const double* __restri
     if (threadIdx.x == 0) status[b] = any ? 4 : 0;
   }
   if (iters && threadIdx.x == 0) iters[b] = 0;
+}
+
+// The whole factored linear inversion of one process on the FP64 matrix cores (round 3; process.py:284-289 with the
+// factored operator above): FOUR 256-thread workgroups per process, workgroup j the 16 columns
+//     beta(j, t) = (t % 8) d + 2 j + t / 8,  t = 0..15      (beta = e d + b: every e, b in {2 j, 2 j + 1})
+// of T and X -- exactly the rows (a, b in {2 j, 2 j + 1}) of the Choi matrix, so nothing is exchanged between them.
+//   stage 1  T[s][beta] = (sum_m n[s][m] V_P^+[beta][m]) / N_s   real x complex: wavefront w the 16 input states
+//            16 w .. 16 w + 15, two accumulator tiles (re, im) x two chains, K = M in steps of 4.  The counts are the A
+//            operand as they come (int64 -> double in the load path), the normalisation by N_s = sum_m n[s][m]
+//            (process.py:285) is applied to the 8 results per lane instead of the M operands: 0 / 0 = NaN as there.
+//   stage 2  X[alpha][beta] = sum_s V_S^+[alpha][s] T[s][beta]   complex x complex (four real products, two chains
+//            each): T through a 17 KB LDS tile, V_S^+ straight from L2 (requested before stage 1 starts).
+//   store    Choi[(a d + b)][(c d + e)] = X[(a d + c)][(e d + b)]: a lane's 16 bytes sit in 128-byte runs (e = t % 8).
+// `vp_perm` [4][M][32] is V_P^+ with the columns of each workgroup side by side (re x 16 | im x 16): k_vp_perm, once per
+// set-up.  Measured at B = 64: k_lifp_freq + k_gemm + k_lifp_kron_finish took 14.7 + 32.9 + 40.9 us (the first product
+// one wavefront per tile with a load round trip per k-step, the second a scalar FMA loop); see profiles/README.md.
+__global__ void k_vp_perm(const double* __restrict__ vp_pinvT, int M, double* __restrict__ vp_perm) {
+  const int total = 4 * M * 32;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int j = t / (M * 32), m = (t / 32) % M, c = t & 31, part = c >> 4, tt = c & 15;
+    const int beta = (tt & 7) * 8 + 2 * j + (tt >> 3);
+    vp_perm[t] = vp_pinvT[((size_t)m * 64 + beta) * 2 + part];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_lifp64(const int64_t* __restrict__ counts, int B, int M,
+                                                const double* __restrict__ vp_perm, const double* __restrict__ vs_pinv,
+                                                double* __restrict__ choi, int32_t* __restrict__ status,
+                                                int32_t* __restrict__ iters) {
+  constexpr int DC = 64, PT = 17, CH = 6;  // CH k-steps are requested while the previous CH run through the matrix pipe
+  __shared__ cd tl[DC * PT];
+  const int b = blockIdx.x >> 2, j = blockIdx.x & 3;
+  if (b >= B) return;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+  const cd* vrow = reinterpret_cast<const cd*>(vs_pinv) + (size_t)(16 * w + r16) * DC + kq;
+  cd va[DC / 4];
+#pragma unroll
+  for (int k = 0; k < DC / 4; ++k) va[k] = vrow[4 * k];
+  const int64_t* crow = counts + ((size_t)b * DC + 16 * w + r16) * M + kq;
+  const double* bp = vp_perm + ((size_t)j * M + kq) * 32 + r16;
+  const int KS = M >> 2;  // (the host sends M % 4 == 0 here)
+  sc_v4f64 tre[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, tim[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  long long a0[CH], a1[CH];  // (raw counts: converted when they are consumed, so that a request does not wait for its data)
+  double p0[CH], q0[CH], p1[CH], q1[CH];
+  double rs = 0.0;
+  auto request = [&](int k0, long long (&a)[CH], double (&p)[CH], double (&q)[CH]) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      a[u] = crow[4 * (k0 + u)];
+      p[u] = bp[(size_t)(k0 + u) * 128];
+      q[u] = bp[(size_t)(k0 + u) * 128 + 16];
+    }
+  };
+  auto consume = [&](const long long (&a)[CH], const double (&p)[CH], const double (&q)[CH]) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const double n = (double)a[u];
+      rs += n;
+      tre[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(n, p[u], tre[u & 1], 0, 0, 0);
+      tim[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(n, q[u], tim[u & 1], 0, 0, 0);
+    }
+  };
+  const int nfull = KS / CH;  // (every condition below is uniform over the workgroup)
+  if (nfull > 0) request(0, a0, p0, q0);
+  for (int c = 0; c < nfull; c += 2) {
+    if (c + 1 < nfull) request((c + 1) * CH, a1, p1, q1);
+    consume(a0, p0, q0);
+    if (c + 2 < nfull) request((c + 2) * CH, a0, p0, q0);
+    if (c + 1 < nfull) consume(a1, p1, q1);
+  }
+  for (int k = nfull * CH; k < KS; ++k) {  // M / 4 not a multiple of CH: the last k-steps one at a time
+    const double n = (double)crow[4 * k];
+    rs += n;
+    tre[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(n, bp[(size_t)k * 128], tre[0], 0, 0, 0);
+    tim[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(n, bp[(size_t)k * 128 + 16], tim[0], 0, 0, 0);
+  }
+  rs += __shfl_xor(rs, 16);
+  rs += __shfl_xor(rs, 32);  // N_s of state 16 w + r16 (a sum of integers: exact in any order)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = kq + 4 * r;
+    const double tot = __shfl(rs, row);
+    tl[(16 * w + row) * PT + r16] = cd{(tre[0][r] + tre[1][r]) / tot, (tim[0][r] + tim[1][r]) / tot};
+  }
+  __syncthreads();
+  sc_v4f64 xre[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, xim[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+  for (int k = 0; k < DC / 4; ++k) {
+    const cd a = va[k], t = tl[(4 * k + kq) * PT + r16];
+    xre[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, t.re, xre[k & 1], 0, 0, 0);
+    xim[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, t.im, xim[k & 1], 0, 0, 0);
+    xre[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, t.im, xre[k & 1], 0, 0, 0);
+    xim[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, t.re, xim[k & 1], 0, 0, 0);
+  }
+  cd* out = reinterpret_cast<cd*>(choi) + (size_t)b * DC * DC;
+  const int e = r16 & 7, bb = 2 * j + (r16 >> 3);
+  bool nan = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int alpha = 16 * w + kq + 4 * r, a = alpha >> 3, c = alpha & 7;
+    const cd x{xre[0][r] + xre[1][r], xim[0][r] + xim[1][r]};
+    out[(a * 8 + bb) * DC + c * 8 + e] = x;
+    nan = nan || !(x.re == x.re);
+  }
+  // an input state without counts makes its frequencies NaN (process.py:285 divides by the sum): its row of T is NaN and
+  // with it every element of X, in every one of the four workgroups -- workgroup 0 reports
+  const bool any = __syncthreads_or(nan);
+  if (j == 0 && threadIdx.x == 0) {
+    if (status) status[b] = any ? 4 : 0;
+    if (iters) iters[b] = 0;
+  }
 }
 
 // 'pgdb' at n = 3 (process.py:291-314, the arithmetic as k_pgdb_batch restates it for n <= 2) through the FACTORED

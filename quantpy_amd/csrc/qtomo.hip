@@ -1557,6 +1557,11 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
     if (int r = enqueue_left_inverse_complex(h, (const double*)ps.emats, M, D, (double*)ps.vp_pinv)) return r;
     HIPCHK(hipMemcpyAsync(&info[1], h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     launch_transpose<2>(h, (const double*)ps.vp_pinv, D, M, (double*)ps.vp_pinvT);
+    if (M % 4 == 0) {  // the operand of k_lifp64 (the matrix-core path of qt_lifp_batch)
+      HIPCHK(hipMalloc(&ps.vp_perm, (size_t)4 * M * 32 * sizeof(double)));
+      hipLaunchKernelGGL(qt::k_vp_perm, dim3(grid_for((size_t)4 * M * 32)), dim3(256), 0, h->stream, (const double*)ps.vp_pinvT, M,
+                         (double*)ps.vp_perm);
+    }
     HIPCHK(hipGetLastError());
     QT_STREAM_SYNC(h);
     if (info[0] != 0) return fail(QT_ERR_SINGULAR, "input states do not span the operator space (column %d)", info[0] - 1);
@@ -1641,22 +1646,28 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
   if (h->proc.factored) {  // n = 3: X = V_S^+ F V_P^+^T, two small products per process (qt_process64.h)
     if ((size_t)B * D > (size_t)1 << 26) return fail(QT_ERR_ARG, "batch too large");
     const int R = D * M;  // 13824: a multiple of 64, the pitch k_lifp_freq pads to
-    HIPCHK(h->ws_x.ensure(((size_t)B * R + 192) * sizeof(double)));
-    HIPCHK(h->ws_g.ensure((size_t)B * D * D * 2 * sizeof(double)));
-    double *F = h->ws_x.as<double>(), *T = h->ws_g.as<double>(), *raw = dchoi;
+    double* raw = dchoi;
     if (cptp) {
       HIPCHK(h->ws_f.ensure((size_t)B * D * D * 2 * sizeof(double)));
       raw = h->ws_f.as<double>();
     }
-    hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 15) / 16), dim3(256), 0, h->stream, dc, B * D, M, D, R, F);
-    // T[(b, s)][beta] = sum_m F[(b, s)][m] V_P^+[beta][m]: real x complex = a real GEMM with 2 D interleaved columns
-    for (int b0 = 0; b0 < B; b0 += 8192) {  // (grid.y <= 65535 row tiles)
-      const int nb = B - b0 < 8192 ? B - b0 : 8192;
-      hipLaunchKernelGGL(qt::k_gemm<0>, dim3(2 * D / 16, (nb * D + 15) / 16), dim3(64), 0, h->stream, nb * D, 2 * D, M,
-                         F + (size_t)b0 * R, M, 0, (const double*)h->proc.vp_pinvT, 2 * D, 0, T + (size_t)b0 * D * D * 2, 2 * D);
+    if (h->proc.vp_perm) {  // M % 4 == 0: both products of a process in one kernel on the matrix cores
+      hipLaunchKernelGGL(qt::k_lifp64, dim3(4 * B), dim3(256), 0, h->stream, dc, B, M, (const double*)h->proc.vp_perm,
+                         (const double*)h->proc.vs_pinv, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
+    } else {
+      HIPCHK(h->ws_x.ensure(((size_t)B * R + 192) * sizeof(double)));
+      HIPCHK(h->ws_g.ensure((size_t)B * D * D * 2 * sizeof(double)));
+      double *F = h->ws_x.as<double>(), *T = h->ws_g.as<double>();
+      hipLaunchKernelGGL(qt::k_lifp_freq, dim3((B * D + 15) / 16), dim3(256), 0, h->stream, dc, B * D, M, D, R, F);
+      // T[(b, s)][beta] = sum_m F[(b, s)][m] V_P^+[beta][m]: real x complex = a real GEMM with 2 D interleaved columns
+      for (int b0 = 0; b0 < B; b0 += 8192) {  // (grid.y <= 65535 row tiles)
+        const int nb = B - b0 < 8192 ? B - b0 : 8192;
+        hipLaunchKernelGGL(qt::k_gemm<0>, dim3(2 * D / 16, (nb * D + 15) / 16), dim3(64), 0, h->stream, nb * D, 2 * D, M,
+                           F + (size_t)b0 * R, M, 0, (const double*)h->proc.vp_pinvT, 2 * D, 0, T + (size_t)b0 * D * D * 2, 2 * D);
+      }
+      hipLaunchKernelGGL(qt::k_lifp_kron_finish, dim3(B), dim3(256), 0, h->stream, (const double*)T,
+                         (const double*)h->proc.vs_pinv, B, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
     }
-    hipLaunchKernelGGL(qt::k_lifp_kron_finish, dim3(B), dim3(256), 0, h->stream, (const double*)T, (const double*)h->proc.vs_pinv,
-                       B, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
     if (cptp) {
       if (int r = allow_big_lds(qt::k_cptp_project64, qt::Proc64::kLdsBytes)) return r;
       HIPCHK(h->proc_ws.ensure((size_t)B * qt::Proc64::kWsComplex * 2 * sizeof(double)));  // Dykstra's p, q, y, x + the clip's input

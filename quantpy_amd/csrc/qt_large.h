@@ -96,20 +96,53 @@ struct Large {
     __syncthreads();
     if ((threadIdx.x & 63) == 0) c.red()[threadIdx.x >> 6] = v;
     __syncthreads();
-    double s = 0.0;
+    if constexpr (NW == 16) {
+      // Round 3: ONE LDS read per wavefront -- lane l takes partial l % 16 (four lanes per address: a broadcast) and the 16
+      // partials are summed on the DPP network; every row of 16 lanes runs the same tree on the same numbers, so every
+      // thread still ends with the same bits.  Sixteen reads per thread were 256 wave-wide LDS instructions per reduction
+      // and workgroup: ~1000 clocks of LDS issue, a third of a round of the BFGS two-loop recursion at n = 5
+      // (scripts/phase_timing_large_bfgs.py).
+      return gsum<16>(c.red()[threadIdx.x & 15]);
+    } else {
+      double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s += c.red()[w];
-    return s;
+      for (int w = 0; w < NW; ++w) s += c.red()[w];
+      return s;
+    }
+  }
+  // The same with ONE barrier, for a loop of reductions with nothing else in the red() scratch: round k uses half k % 2 of
+  // it, so a wavefront that is two rounds ahead is the first that could overwrite what a slow one still reads -- and it
+  // cannot be: it has passed the barrier of the round in between, which the slow one reaches only after its reads.  The
+  // caller puts a barrier before the first round (the standard reductions before it read red()[0..15]) -- one after the
+  // last is not needed: the next standard reduction starts with one.
+  __device__ static double bsum_alt(const Ctx& c, double v, int half) {
+    static_assert(NW <= 16, "two halves of the 32-entry scratch");
+    v = gsum<64>(v);
+    double* r = c.red() + 16 * half;
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if constexpr (NW == 16) {
+      return gsum<16>(r[threadIdx.x & 15]);
+    } else {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += r[w];
+      return s;
+    }
   }
   __device__ static double bmax(const Ctx& c, double v) {
     v = gmax<64>(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) c.red()[threadIdx.x >> 6] = v;
     __syncthreads();
-    double s = c.red()[0];
+    if constexpr (NW == 16) {
+      return gmax<16>(c.red()[threadIdx.x & 15]);
+    } else {
+      double s = c.red()[0];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s = nanmax(s, c.red()[w]);
-    return s;
+      for (int w = 1; w < NW; ++w) s = nanmax(s, c.red()[w]);
+      return s;
+    }
   }
 
   // Result of the workgroup's trial, element (i, j) = r per thread: store it and / or its Hilbert-Schmidt distance to
@@ -909,6 +942,7 @@ k_mle_large_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B,
   const int eval_cap = (max_iter + 2) * 130;
   while (true) {  // uniform: one trial per workgroup, every thread holds the same scalars
     double ft, gt;
+    QT_STAMP(21);  // (profile build, scripts/phase_timing_large_bfgs.py: the slots keep the LAST iteration's clocks)
     // Inlined, with the LDS base and the per-thread indices laundered through an empty asm every iteration: the
     // compiler can then neither hoist the ~100 loop-invariant LDS addresses of the evaluation out of the loop (that is
     // what spilled 1.4 KB per lane when it was first inlined) nor does the kernel pay the callee-saved-register saves of
@@ -927,6 +961,7 @@ k_mle_large_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B,
       ci.xm = c.xm + v0, ci.zm = c.zm + v0, ci.ny = c.ny + v0, ci.pi = c.pi + v0, ci.pj = c.pj + v0;
       S::nll_grad_inl(ci, xk + stp * pk, ft, gt);  // (barriers inside publish the parked line-search state)
     }
+    QT_STAMP(22);
     if (++nfev > eval_cap) {
       status = 2;
       break;
@@ -969,25 +1004,40 @@ k_mle_large_bfgs(PovmView pv, const int64_t* __restrict__ counts, int B,
     my[(size_t)(2 * np + 1) * D] = yk;
     if (c.t == 0) prho[np] = rhok;
     __syncthreads();
+    QT_STAMP(23);
     // two-loop recursion: p = -H_k g with H_0 = I
+    // (round 3: the pair of the NEXT round is requested before this round's reduction; arithmetic and order unchanged.
+    //  Four rounds ahead was measured too: the rings cost 90 more bytes of scratch and the run came out 25 % slower.)
     double q = gk;
+    double si = sk, yi = yk;
     for (int i = np; i >= 0; --i) {
-      const double si = (i == np) ? sk : my[(size_t)(2 * i) * D];
-      const double yi = (i == np) ? yk : my[(size_t)(2 * i + 1) * D];
-      const double a = prho[i] * S::bsum(c, si * q);
+      double sn = 0.0, yn = 0.0;
+      if (i > 0) {
+        sn = my[(size_t)(2 * (i - 1)) * D];
+        yn = my[(size_t)(2 * (i - 1) + 1) * D];
+      }
+      const double a = prho[i] * S::bsum_alt(c, si * q, i & 1);
       if (c.t == 0) palpha[i] = a;
       q = fma(-a, yi, q);
+      if (i > 0) si = sn, yi = yn;  // (the last round's pair, i = 0, is the first of the second loop)
     }
     __syncthreads();
+    QT_STAMP(24);
     for (int i = 0; i <= np; ++i) {
-      const double si = (i == np) ? sk : my[(size_t)(2 * i) * D];
-      const double yi = (i == np) ? yk : my[(size_t)(2 * i + 1) * D];
-      const double bb = prho[i] * S::bsum(c, yi * q);
+      double sn = sk, yn = yk;
+      if (i + 1 < np) {
+        sn = my[(size_t)(2 * (i + 1)) * D];
+        yn = my[(size_t)(2 * (i + 1) + 1) * D];
+      }
+      const double bb = prho[i] * S::bsum_alt(c, yi * q, i & 1);
       q = fma(si, palpha[i] - bb, q);
+      si = sn, yi = yn;
     }
     pk = -q;
+    QT_STAMP(19);
     ls.start(fk, old_old, S::bsum(c, gk * pk), &stp);  // (the barriers of bsum are behind every read of lsb)
     if (c.t == 0) ls.save(lsb);
+    QT_STAMP(20);
   }
   if (status == 0) {
     const double gn = S::bmax(c, fabs(gk));

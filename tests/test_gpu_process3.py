@@ -299,3 +299,47 @@ def test_n3_pgdb_pieces_at_general_points(g3):
     lhs = float(np.dot(p_d, w))
     rhs = -float(np.real(np.sum(np.conj(g_c) * dd)))
     assert abs(lhs - rhs) < 1e-11 * abs(lhs), (lhs, rhs)
+
+
+@pytest.mark.parametrize("pieces", [1, 3, 5, 9])
+def test_n3_lifp_both_kernel_paths_against_the_factor_formula(g3, pieces):
+    """qt_lifp_batch at n = 3 for POVMs with M % 4 == 0 (k_lifp64: both products of a process in one matrix-core kernel;
+    M / 4 a multiple of its look-ahead chunk or not) and M % 4 != 0 (k_lifp_freq + k_gemm + k_lifp_kron_finish), against
+    X = V_S^+ F V_P^+^T and Choi[(a, b)][(c, e)] = X[(a, c)][(e, b)] evaluated in NumPy with the engine's own factors
+    (which test_n3_factored_left_inverse_is_the_references pins to the reference for the 'proj-set' POVM).  The POVM: all
+    216 'proj-set' elements as ONE measurement (each / 27), its last element split into `pieces` equal parts --
+    M = 216 (54 k-steps, no tail), 218 (fallback), 220 (55 k-steps: one in the tail loop), 224 (56: two)."""
+    import quantpy_amd as qp
+    from quantpy_amd import _capi
+
+    tmg = _tomograph(qp, g3, "Q0")
+    first = tmg.tomographs[0]
+    rows = np.asarray(first.povm_matrix, dtype=np.float64).reshape(-1, 64) / 27.0
+    rows = np.concatenate([rows[:-1]] + [rows[-1:] / pieces] * pieces)
+    M = rows.shape[0]
+    assert M == 215 + pieces
+    eng = qp.get_engine(3)
+    eng.set_povm(rows[None], 10000 * 27)
+    eng.process_setup(np.stack([np.asarray(s.matrix, dtype=np.complex128) for s in tmg.input_basis.elements]))
+    d, D = 8, 64
+    vs = np.empty((D, D), dtype=np.complex128)
+    vp = np.empty((D, M), dtype=np.complex128)
+    assert eng.lib.qt_process_get_factors(eng._h, vs.ctypes.data, vp.ctypes.data, _capi.QT_HOST_PTR) == 0
+    rng = np.random.default_rng(pieces)
+    B = 5
+    counts = rng.integers(0, 4000, size=(B, D, 1, M)).astype(np.int64)
+    counts[3, :, 0, ::7] = 0  # zeros among the counts are ordinary numbers
+    got, iters = eng.lifp(counts, cptp=False, return_iters=True)
+    assert list(iters) == [0] * B
+    a, b, c, e = np.meshgrid(np.arange(d), np.arange(d), np.arange(d), np.arange(d), indexing="ij")
+    for k in range(B):
+        f = counts[k, :, 0, :] / counts[k, :, 0, :].sum(axis=1, keepdims=True)
+        x = vs @ f @ vp.T
+        want = np.empty((D, D), dtype=np.complex128)
+        want[(a * d + b).ravel(), (c * d + e).ravel()] = x[(a * d + c).ravel(), (e * d + b).ravel()]
+        assert np.abs(got[k] - want).max() < 1e-11 * max(1.0, np.abs(want).max()), (pieces, k, np.abs(got[k] - want).max())
+    # one process of a batch alone gives the same bits, and an input state without counts is NaN for its process only
+    assert np.array_equal(eng.lifp(counts[2], cptp=False), got[2])
+    counts[1, 40] = 0
+    again = eng.lifp(counts, cptp=False)
+    assert np.isnan(again[1]).all() and np.array_equal(again[[0, 2, 3, 4]], got[[0, 2, 3, 4]])

@@ -247,11 +247,15 @@ int qt_mhmc_state(qt_handle_t* h, const int64_t* counts, int C, const double* x_
 int qt_process_setup(qt_handle_t* h, const double* in_states, int flags);
 /* lifp_oper[D*M][D^2][2] (nullable) and its left inverse [D^2][D*M][2] (nullable) */
 int qt_process_get_operators(qt_handle_t* h, double* lifp_oper, double* lifp_oper_inv, int flags);
-/* n = 3: the design matrix is kept Kronecker-factored, L = (V_S (x) V_P) Pi^T with V_S = [vec rho_s] (D x D) and
+/* n = 3 (and n = 2 beside the dense form): the design matrix Kronecker-factored, L = (V_S (x) V_P) Pi^T with V_S = [vec rho_s] (D x D) and
  * V_P = [vec E_m] (M x D, column e d + b <-> E_m[e][b]), so that L^+ = Pi (V_S^+ (x) V_P^+) (plain transposes,
  * routines.py:69-71): vs_pinv[D][D][2], vp_pinv[D][M][2] (each nullable).  Entry [(c d + e) D + (a d + b)][s M + m] of
  * the reference's `_lifp_oper_inv` is vs_pinv[a d + c][s] * vp_pinv[e d + b][m]. */
 int qt_process_get_factors(qt_handle_t* h, double* vs_pinv, double* vp_pinv, int flags);
+/* n = 2 keeps BOTH forms: the dense operator (qt_process_get_operators, 'pgdb', the process chain) and, when M % 4 == 0,
+ * the factors, which qt_lifp_batch multiplies by (34 matrix instructions per process instead of 288; same Choi matrix
+ * to rounding).  on != 0 makes qt_lifp_batch use the dense left inverse instead (A/B measurements, tests). */
+int qt_process_prefer_dense(qt_handle_t* h, int on);
 /* counts[B][D][S][K] -> choi[B][D][D][2] (process.py:284-289); cptp != 0 applies the Dykstra
  * projection of process.py:231-257 (n_iter <= 1000, stop 1e-12); iters[B] (nullable) */
 int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double* choi, int32_t* iters,

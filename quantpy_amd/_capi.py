@@ -72,6 +72,7 @@ SIGNATURES = {
     "qt_process_setup": (_c_int, [_vp, _vp, _c_int]),
     "qt_process_get_operators": (_c_int, [_vp, _vp, _vp, _c_int]),
     "qt_process_get_factors": (_c_int, [_vp, _vp, _vp, _c_int]),
+    "qt_process_prefer_dense": (_c_int, [_vp, _c_int]),
     "qt_lifp_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _c_int]),
     "qt_pgdb_batch": (_c_int, [_vp, _vp, _c_int, _c_int, _c_dbl, _c_int, _vp, _vp, _vp, _c_int]),
     "qt_mhmc_process": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _c_int]),

@@ -31,7 +31,8 @@ struct ProcessState {
   void* vs_pinv = nullptr;   // [D][D] complex: left inverse of V_S = [vec rho_s]
   void* vp_pinv = nullptr;   // [D][M] complex: left inverse of V_P = [vec E_m] (index e d + b)
   void* vp_pinvT = nullptr;  // [M][D] complex: its transpose, the right-hand operand of T = F V_P^+^T
-  void* vp_perm = nullptr;   // [4][M][32] real: the same, columns grouped per workgroup of k_lifp64 (M % 4 == 0 only)
+  void* vp_perm = nullptr;   // [groups][M][32] real: the same, 16 columns (re | im) per group in the order k_lifp64 (n = 3:
+                             // 4 groups) / k_lifp16 (n = 2: 1 group) store them; M % 4 == 0 only
   bool factored = false;
   size_t cap_rows = 0;
   void release() {
@@ -849,6 +850,102 @@ __global__ void __launch_bounds__(512) k_lifp_gemm(const double* __restrict__ F,
 }
 
 // mode 0: Dykstra CPTP, 1: TP only, 2: CP only  (process.py:231-278)
+// ---- Linear inversion through the Kronecker factors of the design matrix (round 3) -------------------------------
+// process.py:203-208 builds rows vec(rho_s (x) E_m^T); up to a fixed permutation of the columns that is
+// vec(rho_s) (x) vec(E_m), and with PLAIN transposes (routines.py:69-71) the left inverse of a Kronecker product is the
+// Kronecker product of the left inverses (qt_process64.h has the derivation; n = 3 has always run this way):
+//     X = V_S^+ . F . V_P^+^T,      Choi[(a d + b)][(c d + e)] = X[(a d + c)][(e d + b)],
+// V_S = [vec rho_s] (D x D), V_P = [vec E_m] (M x D), F[s][m] the frequencies.  At n = 2 that is 34 matrix instructions
+// per process (real x complex 16 x M x 16, then complex 16 x 16 x 16) where the dense operator costs 288 -- the dense
+// GEMM of k_lifp_gemm reads a 2.4 MB operand per 64 processes to do 8.5 x the arithmetic -- and the kernel becomes what
+// SURVEY 8d expected of this path: a stream of counts in (8 D M bytes per process) and Choi matrices out (16 D^2).
+//
+// ONE wavefront per process, no LDS traffic between the products: v_mfma_f64_16x16x4_f64 leaves rows kq + 4 r of a
+// 16 x 16 tile in accumulator element r of lane (kq, r16) -- exactly the element the B operand of k-step r wants from that
+// lane (row 4 r + kq) -- so T = F V_P^+^T feeds X = V_S^+ T straight from its accumulators.  The counts are the A operand
+// of the first product as they come (int64 -> double on the way), the normalisation by N_s (process.py:285) is applied
+// to T's 8 numbers per lane (0 / 0 = NaN as there); V_P^+^T waits in LDS (`vp_perm`: [M][32], columns ordered
+// beta(t) = (t % d) d + t / d so that a lane's result sits in 64-byte runs of a Choi row), V_S^+ in registers.
+// KSC = M / 4 at compile time (9 for the 'proj-set' POVM: every load of a process in flight at once) or 0.
+__global__ void k_vp_perm(const double* __restrict__ vp_pinvT, int M, int D, int d, int groups, double* __restrict__ vp_perm) {
+  const int total = groups * M * 32, per = 16 / d;  // `per` values of b per group of 16 columns
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int j = t / (M * 32), m = (t / 32) % M, c = t & 31, part = c >> 4, tt = c & 15;
+    const int beta = (tt % d) * d + per * j + tt / d;
+    vp_perm[t] = vp_pinvT[((size_t)m * D + beta) * 2 + part];
+  }
+}
+
+template <int KSC>
+__global__ void __launch_bounds__(256) k_lifp16(const int64_t* __restrict__ counts, int B, int M,
+                                                const double* __restrict__ vp_perm, const double* __restrict__ vs_pinv,
+                                                double* __restrict__ choi, int32_t* __restrict__ status,
+                                                int32_t* __restrict__ iters) {
+  constexpr int DC = 16;
+  extern __shared__ double s_vp[];  // [M][32]
+  for (int k = threadIdx.x; k < M * 32; k += 256) s_vp[k] = vp_perm[k];
+  const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
+  cd va[4];  // A operand of the second product: V_S^+[alpha = r16][s = 4 r + kq]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) va[r] = reinterpret_cast<const cd*>(vs_pinv)[r16 * DC + 4 * r + kq];
+  __syncthreads();
+  const int KS = KSC > 0 ? KSC : (M >> 2);
+  const double* bp = s_vp + kq * 32 + r16;
+  const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+  for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {  // (wave-uniform)
+    const int64_t* crow = counts + ((size_t)b * DC + r16) * M + kq;
+    v4f64 tre[2] = {z, z}, tim[2] = {z, z};
+    double rs = 0.0;
+    if constexpr (KSC > 0) {
+      long long n[KSC];
+#pragma unroll
+      for (int k = 0; k < KSC; ++k) n[k] = crow[4 * k];
+#pragma unroll
+      for (int k = 0; k < KSC; ++k) {
+        const double dn = (double)n[k];
+        rs += dn;
+        tre[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(dn, bp[k * 128], tre[k & 1], 0, 0, 0);
+        tim[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(dn, bp[k * 128 + 16], tim[k & 1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int k = 0; k < KS; ++k) {
+        const double dn = (double)crow[4 * k];
+        rs += dn;
+        tre[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(dn, bp[k * 128], tre[k & 1], 0, 0, 0);
+        tim[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(dn, bp[k * 128 + 16], tim[k & 1], 0, 0, 0);
+      }
+    }
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);  // N_s of input state r16 (a sum of integers: exact in any order)
+    v4f64 xr1 = z, xr2 = z, xi1 = z, xi2 = z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double tot = __shfl(rs, kq + 4 * r);
+      const double tr = (tre[0][r] + tre[1][r]) / tot, ti = (tim[0][r] + tim[1][r]) / tot;  // T[4 r + kq][beta(r16)]
+      xr1 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[r].re, tr, xr1, 0, 0, 0);
+      xr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-va[r].im, ti, xr2, 0, 0, 0);
+      xi1 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[r].re, ti, xi1, 0, 0, 0);
+      xi2 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[r].im, tr, xi2, 0, 0, 0);
+    }
+    cd* out = reinterpret_cast<cd*>(choi) + (size_t)b * DC * DC;
+    const int e = r16 & 3, bb = r16 >> 2;
+    bool nan = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int alpha = kq + 4 * r, a = alpha >> 2, c = alpha & 3;
+      const cd x{xr1[r] + xr2[r], xi1[r] + xi2[r]};
+      out[(a * 4 + bb) * DC + c * 4 + e] = x;
+      nan = nan || !(x.re == x.re);
+    }
+    const bool any = __any(nan);  // (an input state without counts: NaN frequencies, process.py:285)
+    if (lane == 0) {
+      if (status) status[b] = any ? 4 : 0;
+      if (iters) iters[b] = 0;
+    }
+  }
+}
+
 template <int DC>
 __global__ void __launch_bounds__(ProcWG<DC>::NT, 4) k_cptp_project(const double* __restrict__ in, int B, int mode,
                                                                 int n_iter, double tol, double* __restrict__ out,

@@ -65,11 +65,8 @@ struct Proc64 {
   // grid are computed and the 6 below are written as their mirror images.  Which wavefront computes what is decoupled
   // there from which thread owns which element: wavefronts 0, 1 take two tiles each (row 0), the other six one each,
   // i.e. 3 + 3 + 2 + 2 tiles on the four SIMDs (wavefronts w and w + 4 share one) instead of 4 each.
-  // X' = X W is NOT mirrored although it is Hermitian too up to the commutator of X with the rounded Y: measured (GPU and
-  // a NumPy model of the same iteration, scripts/cp_accuracy_probe.py), replacing its lower tiles by the mirror of the
-  // upper ones takes the agreement with an eigh-based clip from 1e-15 to 1e-11 -- the substitution injects a
-  // non-commuting perturbation every step and the iteration has no contraction for those.  It is computed in full, each
-  // wavefront its own two tiles.
+  // Since round 3 X' = X W is computed the same way (round 2 computed it in full, each wavefront its own two tiles,
+  // because mirroring it had cost four digits: clip() below has what was wrong with that mirror, and with not mirroring).
   struct Work {
     int row0, col0, r16, kq;
     bool two;  // a second tile at col0 + 16
@@ -123,10 +120,6 @@ struct Proc64 {
   // the Hermitian products: this wavefront's share of the upper tiles
   __device__ __forceinline__ static void tile_product(const cd* A, const cd* B, const Work& wk, cd (&c)[EPT]) {
     tiles(A, B, wk.row0, wk.col0, wk.two, wk.r16, wk.kq, c);
-  }
-  // a general product: this wavefront's own two tiles (element r of the result in c[r])
-  __device__ __forceinline__ static void own_product(const cd* A, const cd* B, const Map& m, cd (&c)[EPT]) {
-    tiles(A, B, m.row0, m.col0, true, m.r16, m.kq, c);
   }
 
   // the computed tile(s) into image D, and their conjugate transposes into the mirror positions below the diagonal
@@ -274,18 +267,25 @@ struct Proc64 {
     int ns_left = 12, steps = 0;
     const Work wk(m.tid);  // (derived from the caller's re-derived thread index: see dykstra)
     const int wave = m.tid >> 6;
-    // A step (round 3: three barriers where there were six, and a lifting polynomial of degree 5).
+    // A step (round 3: EVERY product Hermitian, three barriers where there were six, a lifting polynomial of degree 5).
     //   phase 1  Y = X X on the upper tiles, mirrored (store_hermitian); res = ||I - Y||_F^2 out of the accumulators.
-    //   lifting  x <- x (3 - 3.25 x^2 + 1.25 x^4):  Z = Y Y (Hermitian again: upper tiles), W' = -3.25 Y + 1.25 Z written over Y
-    //            by the wavefronts that own the tiles, X <- 3 X + X W'.
-    //   Newton-Schulz  X <- 1.5 X - 0.5 X Y, finished in the accumulators of the product.
-    // The cubic 1.9 x - 0.9 x^3 (round 2; qt_signclip_wg.h explains why not 2 x - x^3 at d = 64) grows an unlifted
-    // eigenvalue by 1.9 for 3 + 4 tile products per SIMD (a Hermitian product occupies the busiest matrix pipe for 3 tiles, a
-    // general one for 4); the quintic by 3.0 for 3 + 3 + 4: 0.110 against 0.092 e-foldings per tile product.  It is the odd
-    // quintic with p(1) = 1, p'(1) = -1/2 (lifted eigenvalues settle on 1 geometrically, so res ends up measuring the
-    // stragglers only) and slope 3 at 0; slope 3.2 is where the invariant interval [0, 1.26] is lost
-    // (scripts/sign_schedule_model.py: same clip to 1e-14, same Dykstra counts, 10 % fewer tile products on the fixtures'
-    // five clips; the steps are bound by the matrix pipe's throughput, profiles/README.md).
+    //   lifting  x <- x (3 - 3.25 x^2 + 1.25 x^4):  Z = Y Y, W' = -3.25 Y + 1.25 Z written over Y by the wavefronts that own
+    //            the tiles, X <- 3 X + X W'.
+    //   Newton-Schulz  X <- 1.5 X - 0.5 X Y.
+    //   Both finish in the accumulators of the product's UPPER tiles and are stored like Y: mirrored, diagonal tiles
+    //   replaced by their Hermitian part.
+    // Why the new X may be mirrored after all (round 2 computed it in full: mirroring had cost four digits): the product X W
+    // is Hermitian only up to rounding, and its anti-Hermitian part N is not harmless noise -- the rows of N that belong to a
+    // still-unlifted eigen-direction are multiplied by the lifting slope with everything else, step after step (1e-16 becomes
+    // 1e-8 over the 22 steps that lift an eigenvalue of 1e-10 ||A||).  With X computed in full N stayed in X, and the mirrored
+    // Y turned it into a HERMITIAN perturbation of the iteration: 1e-9 on a geometric spectrum down to 1e-10 ||A||, 6e-6 on
+    // a matrix of exact rank 32 (GPU and the NumPy model, scripts/sign_schedule_model.py).  Round 2's mirrored X kept the
+    // diagonal tiles as computed, i.e. kept N inside them (2e-10 on the same spectrum).  Taking the Hermitian part of
+    // EVERY iterate -- upper tiles mirrored, diagonal tiles symmetrised in the wavefront that computed them -- removes N
+    // where it arises: 1e-16 on all of these, and a step is 3 + 3 (+ 3) tile products per SIMD instead of 3 + 4 (+ 3).
+    // The quintic: the odd one with p(1) = 1, p'(1) = -1/2 (lifted eigenvalues settle on 1 geometrically, so res ends up
+    // measuring the stragglers only) and slope 3 at 0; slope 3.2 is where the invariant interval [0, 1.26] is lost.  It
+    // grows an unlifted eigenvalue by 3.0 for 9 tile products where 1.9 x - 0.9 x^3 (round 2) took 6 for 1.9.
     for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (identical bits in every thread)
       cd pr[EPT];
       tile_product(X, X, wk, pr);
@@ -309,15 +309,18 @@ struct Proc64 {
         __syncthreads();
         alpha = 3.0, beta = 1.0;
       }
-      own_product(X, Y, m, pr);
+      tile_product(X, Y, wk, pr);
 #pragma unroll
-      for (int r = 0; r < EPT; ++r) {
-        const cd x = X[e[r]];
-        pr[r] = cd{fma(beta, pr[r].re, alpha * x.re), fma(beta, pr[r].im, alpha * x.im)};
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !wk.two) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const cd x = X[(wk.row0 + wk.kq + 4 * r) * P + wk.col0 + 16 * t + wk.r16];
+          pr[4 * t + r] = cd{fma(beta, pr[4 * t + r].re, alpha * x.re), fma(beta, pr[4 * t + r].im, alpha * x.im)};
+        }
       }
       __syncthreads();  // every wavefront has read X and Y
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) X[e[r]] = pr[r];
+      (void)store_hermitian(X, wk, pr);
       __syncthreads();
       ++steps;
       if (last || !(res == res)) break;
@@ -563,18 +566,9 @@ __global__ void __launch_bounds__(256) k_lifp_kron_finish(const double* __restri
 //   stage 2  X[alpha][beta] = sum_s V_S^+[alpha][s] T[s][beta]   complex x complex (four real products, two chains
 //            each): T through a 17 KB LDS tile, V_S^+ straight from L2 (requested before stage 1 starts).
 //   store    Choi[(a d + b)][(c d + e)] = X[(a d + c)][(e d + b)]: a lane's 16 bytes sit in 128-byte runs (e = t % 8).
-// `vp_perm` [4][M][32] is V_P^+ with the columns of each workgroup side by side (re x 16 | im x 16): k_vp_perm, once per
-// set-up.  Measured at B = 64: k_lifp_freq + k_gemm + k_lifp_kron_finish took 14.7 + 32.9 + 40.9 us (the first product
+// `vp_perm` [4][M][32] is V_P^+ with the columns of each workgroup side by side (re x 16 | im x 16): k_vp_perm
+// (qt_process.h), once per set-up.  Measured at B = 64: k_lifp_freq + k_gemm + k_lifp_kron_finish took 14.7 + 32.9 + 40.9 us (the first product
 // one wavefront per tile with a load round trip per k-step, the second a scalar FMA loop); see profiles/README.md.
-__global__ void k_vp_perm(const double* __restrict__ vp_pinvT, int M, double* __restrict__ vp_perm) {
-  const int total = 4 * M * 32;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-    const int j = t / (M * 32), m = (t / 32) % M, c = t & 31, part = c >> 4, tt = c & 15;
-    const int beta = (tt & 7) * 8 + 2 * j + (tt >> 3);
-    vp_perm[t] = vp_pinvT[((size_t)m * 64 + beta) * 2 + part];
-  }
-}
-
 __global__ void __launch_bounds__(256) k_lifp64(const int64_t* __restrict__ counts, int B, int M,
                                                 const double* __restrict__ vp_perm, const double* __restrict__ vs_pinv,
                                                 double* __restrict__ choi, int32_t* __restrict__ status,

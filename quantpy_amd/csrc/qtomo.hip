@@ -109,6 +109,7 @@ struct qt_handle {
   // process tomography
   qt::ProcessState proc;
   bool proc_set = false;
+  bool proc_dense = false;  // qt_process_prefer_dense: qt_lifp_batch multiplies by the dense left inverse where it has a choice
 
   double ns_tot = 0.0;  // sum of the registered shots per setting
   bool check_shots = true;  // qt_set_option(QT_OPT_SHOTS_CHECK) / QTOMO_SKIP_SHOTS_CHECK=1 at qt_create
@@ -1560,7 +1561,7 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
     if (M % 4 == 0) {  // the operand of k_lifp64 (the matrix-core path of qt_lifp_batch)
       HIPCHK(hipMalloc(&ps.vp_perm, (size_t)4 * M * 32 * sizeof(double)));
       hipLaunchKernelGGL(qt::k_vp_perm, dim3(grid_for((size_t)4 * M * 32)), dim3(256), 0, h->stream, (const double*)ps.vp_pinvT, M,
-                         (double*)ps.vp_perm);
+                         D, d, 4, (double*)ps.vp_perm);
     }
     HIPCHK(hipGetLastError());
     QT_STREAM_SYNC(h);
@@ -1597,11 +1598,31 @@ int qt_process_setup(qt_handle_t* h, const double* in_states, int flags) {
     hipLaunchKernelGGL(qt::k_choi_order_rows, dim3(grid_for(R * C2)), dim3(256), 0, h->stream, (const double*)pinvT, R, D,
                        (double*)ps.pinvR);
   }
-  int info = 0;
+  int info = 0, finfo[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  const bool factors = h->nq == 2 && M % 4 == 0 && (size_t)M * 32 * sizeof(double) <= 64 * 1024;
+  if (factors) {
+    // the Kronecker factors of the left inverse (qt_process.h, k_lifp16): what qt_lifp_batch multiplies by at n = 2; the
+    // dense operators above stay for qt_process_get_operators, 'pgdb' and the process chain
+    HIPCHK(hipMalloc(&ps.vs_pinv, (size_t)D * D * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&ps.vp_pinv, (size_t)D * M * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&ps.vp_pinvT, (size_t)M * D * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&ps.vp_perm, (size_t)M * 32 * sizeof(double)));
+    if (int r = enqueue_left_inverse_complex(h, (const double*)ps.in_states, D, D, (double*)ps.vs_pinv)) return r;
+    HIPCHK(hipMemcpyAsync(&finfo[0], h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (int r = enqueue_left_inverse_complex(h, (const double*)ps.emats, M, D, (double*)ps.vp_pinv)) return r;
+    HIPCHK(hipMemcpyAsync(&finfo[1], h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    launch_transpose<2>(h, (const double*)ps.vp_pinv, D, M, (double*)ps.vp_pinvT);
+    hipLaunchKernelGGL(qt::k_vp_perm, dim3(grid_for((size_t)M * 32)), dim3(256), 0, h->stream, (const double*)ps.vp_pinvT, M, D, d,
+                       1, (double*)ps.vp_perm);
+  }
   HIPCHK(hipGetLastError());
   QT_STREAM_SYNC(h);
   if (info != 0) return fail(QT_ERR_SINGULAR, "process design matrix is rank deficient (column %d): input states x POVM not complete", info - 1);
+  if (factors && (finfo[0] != 0 || finfo[1] != 0)) {  // (cannot happen when the Kronecker product itself has full rank)
+    (void)hipFree(ps.vp_perm);
+    ps.vp_perm = nullptr;
+  }
   h->proc_set = true;
   return 0;
 }
@@ -1619,10 +1640,18 @@ int qt_process_get_operators(qt_handle_t* h, double* lifp_oper, double* lifp_ope
   return finish(h, flags);
 }
 
+int qt_process_prefer_dense(qt_handle_t* h, int on) {
+  QT_ENTER(h);
+  h->proc_dense = on != 0;
+  return 0;
+}
+
 int qt_process_get_factors(qt_handle_t* h, double* vs_pinv, double* vp_pinv, int flags) {
   QT_ENTER(h);
   if (!h->proc_set) return fail(QT_ERR_STATE, "qt_process_setup has not been called");
-  if (!h->proc.factored) return fail(QT_ERR_UNSUPPORTED, "the design matrix is dense for n <= 2 (qt_process_get_operators)");
+  if (!h->proc.vs_pinv || !h->proc.vp_pinv)
+    return fail(QT_ERR_UNSUPPORTED, "this set-up keeps the dense operator only (n = 1, or a POVM with M % 4 != 0 at n = 2): "
+                                    "qt_process_get_operators");
   const hipMemcpyKind kind = (flags & QT_DEVICE_PTR) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   if (vs_pinv) HIPCHK(hipMemcpyAsync(vs_pinv, h->proc.vs_pinv, (size_t)h->D * h->D * 2 * sizeof(double), kind, h->stream));
   if (vp_pinv) HIPCHK(hipMemcpyAsync(vp_pinv, h->proc.vp_pinv, (size_t)h->D * h->M * 2 * sizeof(double), kind, h->stream));
@@ -1688,6 +1717,26 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
   if (D == 4) {
     hipLaunchKernelGGL(qt::k_lifp_batch<4>, dim3(B), dim3(qt::ProcWG<4>::NT), dyn, h->stream, dc, B, M,
                        (const double*)h->proc.pinvT, cptp, dchoi, dit, dst);
+  } else if (h->proc.vp_perm && !h->proc_dense) {
+    // n = 2 through the Kronecker factors of the left inverse: one wavefront per process (qt_process.h, k_lifp16)
+    double* raw = dchoi;
+    if (cptp) {
+      HIPCHK(h->ws_g.ensure((size_t)B * 256 * 2 * sizeof(double)));
+      raw = h->ws_g.as<double>();
+    }
+    int grid = (B + 3) / 4;
+    if (grid > 4096) grid = 4096;  // (16 workgroups per CU; the wavefronts stride over the batch)
+    const size_t lds = (size_t)M * 32 * sizeof(double);
+    int32_t *st = cptp ? (int32_t*)nullptr : dst, *it0 = cptp ? (int32_t*)nullptr : dit;
+    if (M == 36)
+      hipLaunchKernelGGL(qt::k_lifp16<9>, dim3(grid), dim3(256), lds, h->stream, dc, B, M, (const double*)h->proc.vp_perm,
+                         (const double*)h->proc.vs_pinv, raw, st, it0);
+    else
+      hipLaunchKernelGGL(qt::k_lifp16<0>, dim3(grid), dim3(256), lds, h->stream, dc, B, M, (const double*)h->proc.vp_perm,
+                         (const double*)h->proc.vs_pinv, raw, st, it0);
+    if (cptp)
+      hipLaunchKernelGGL(qt::k_cptp_project<16>, dim3(B), dim3(qt::ProcWG<16>::NT), 0, h->stream, (const double*)raw, B, 0,
+                         1000, 1e-12, dchoi, dit, dst);
   } else if (B >= 256 && gemm_lds <= 152 * 1024) {
     // many processes: frequencies, then one FP64 MFMA GEMM over the batch, then (cptp) the projection kernel
     constexpr int NE = 256;

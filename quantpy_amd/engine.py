@@ -289,6 +289,18 @@ class Engine:
         self._chk(self.lib.qt_process_get_operators(self._h, _ptr(oper), _ptr(inv), _capi.QT_HOST_PTR))
         return oper, inv
 
+    def process_prefer_dense(self, on=True):
+        """n = 2 keeps the dense left inverse AND its Kronecker factors; `lifp` multiplies by the factors unless this is
+        switched on (A/B measurements, tests of the dense-operator kernels)."""
+        self._chk(self.lib.qt_process_prefer_dense(self._h, int(bool(on))))
+
+    def process_factors(self):
+        """(V_S^+ (D, D), V_P^+ (D, M)): the Kronecker factors of the left inverse (n = 3; n = 2 when M % 4 == 0)."""
+        vs = np.empty((self.D, self.D), dtype=np.complex128)
+        vp = np.empty((self.D, self.M), dtype=np.complex128)
+        self._chk(self.lib.qt_process_get_factors(self._h, _ptr(vs), _ptr(vp), _capi.QT_HOST_PTR))
+        return vs, vp
+
     def lifp(self, counts, cptp=True, return_iters=False):
         """counts (B, D, S, K) or (D, S, K) -> Choi (B, D, D) / (D, D)."""
         c = _i64(counts)

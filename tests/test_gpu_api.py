@@ -231,9 +231,10 @@ def test_routines_on_gpu(qp, oracle):
 
 
 def test_lifp_batched_gemm_path_matches_fused_kernel_and_oracle(qp, oracle):
-    """n = 2, B >= 256: frequencies + FP64 MFMA GEMM over the batch (+ projection kernel) against the one-process-
-    per-workgroup kernel the small batches use, and against the oracle on a few trials; a ragged batch size
-    (not a multiple of 16) exercises the row guards."""
+    """n = 2 through the DENSE left inverse (qt_process_prefer_dense; the path of POVMs with M % 4 != 0), B >= 256:
+    frequencies + FP64 MFMA GEMM over the batch (+ projection kernel) against the one-process-per-workgroup kernel the
+    small batches use, against the oracle on a few trials, and against the default path through the Kronecker factors of
+    the left inverse (k_lifp16); a ragged batch size (not a multiple of 16) exercises the row guards."""
     np.random.seed(31)
     tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.3, 2))
     tmg.experiment(5000, "proj-set")
@@ -248,12 +249,18 @@ def test_lifp_batched_gemm_path_matches_fused_kernel_and_oracle(qp, oracle):
     ins = oracle.input_states("proj4", 2)
     a = oracle.measurement_matrix("proj-set", 2)
     for cptp in (False, True):
+        eng.process_prefer_dense(True)
         big, it_big = eng.lifp(counts, cptp=cptp, return_iters=True)  # GEMM path
         small = [eng.lifp(counts[lo:lo + 100], cptp=cptp, return_iters=True) for lo in range(0, b, 100)]  # fused kernel
+        eng.process_prefer_dense(False)
         ref = np.concatenate([s[0] for s in small])
         it_ref = np.concatenate([s[1] for s in small])
         assert np.abs(big - ref).max() < 1e-12
         assert np.array_equal(it_big, it_ref)
+        fac, it_fac = eng.lifp(counts, cptp=cptp, return_iters=True)  # the factors: one wavefront per process
+        assert np.abs(fac - big).max() < (1e-9 if cptp else 1e-11), np.abs(fac - big).max()
+        assert np.array_equal(it_fac, it_big)
+        assert np.array_equal(eng.lifp(counts[5], cptp=cptp), fac[5])  # a process alone: the same bits
         for t in (0, 1, b - 1):
             want = oracle.lifp_estimate(counts[t], a, ins)
             if cptp:
@@ -262,9 +269,27 @@ def test_lifp_batched_gemm_path_matches_fused_kernel_and_oracle(qp, oracle):
     # enough blocks of 64 processes for a workgroup to take several of them with one staged operand slice
     b2 = 2100
     counts2 = rng.multinomial(5000, np.full(4, 0.25), size=(b2, 16, nset)).astype(np.int64)
+    eng.process_prefer_dense(True)
     big = eng.lifp(counts2, cptp=False)
     ref = np.concatenate([eng.lifp(counts2[lo:lo + 200], cptp=False) for lo in range(0, b2, 200)])
+    eng.process_prefer_dense(False)
     assert np.abs(big - ref).max() < 1e-12
+    assert np.abs(eng.lifp(counts2, cptp=False) - big).max() < 1e-11
+    # more processes than resident wavefronts (the grid is capped: wavefronts stride over the batch), and the factors
+    # themselves: entry [(c d + e) D + (a d + b)][s M + m] of the dense left inverse is V_S^+[a d + c][s] V_P^+[e d + b][m]
+    b3 = 16384 + 37
+    counts3 = rng.multinomial(5000, np.full(4, 0.25), size=(b3, 16, nset)).astype(np.int64)
+    many = eng.lifp(counts3, cptp=False)
+    assert np.array_equal(many[[0, 4096 * 4, b3 - 1]], eng.lifp(counts3[[0, 4096 * 4, b3 - 1]], cptp=False))
+    assert np.isfinite(many).all()
+    vs, vp = eng.process_factors()
+    _, inv = eng.process_operators()
+    d, dd, mm = 4, 16, nset * 4
+    a_, b_, c_, e_ = np.meshgrid(np.arange(d), np.arange(d), np.arange(d), np.arange(d), indexing="ij")
+    kron = np.einsum("xs,ym->xysm", vs, vp)  # [alpha][beta][s][m]
+    want = np.empty((dd * dd, dd * mm), dtype=np.complex128)
+    want[((c_ * d + e_) * dd + (a_ * d + b_)).ravel()] = kron[(a_ * d + c_).ravel(), (e_ * d + b_).ravel()].reshape(-1, dd * mm)
+    assert np.abs(want - inv).max() < 1e-9 * np.abs(inv).max()
 
 
 def test_lifp_batched_ragged_povm_and_nan_isolation(qp):

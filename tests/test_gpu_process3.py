@@ -343,3 +343,40 @@ def test_n3_lifp_both_kernel_paths_against_the_factor_formula(g3, pieces):
     counts[1, 40] = 0
     again = eng.lifp(counts, cptp=False)
     assert np.isnan(again[1]).all() and np.array_equal(again[[0, 2, 3, 4]], got[[0, 2, 3, 4]])
+
+
+def test_n3_cp_step_on_hard_spectra():
+    """The CP step of k_cptp_project64 (sign-function clip: degree-5 lifting, Newton-Schulz finish) against an eigh-based
+    clip (process.py:270-277) on spectra the fixtures do not have: eigenvalues down to 1e-10 of the norm with both signs,
+    exact zeros (rank-deficient, where sign(0) = 0 leaves eps / 2 instead of eps: 5e-13), negative definite, a multiple
+    of the identity, one dominant eigenvalue over a tiny bulk, and the zero matrix."""
+    import quantpy_amd as qp
+
+    rng = np.random.default_rng(2024)
+    g = rng.standard_normal((64, 64)) + 1j * rng.standard_normal((64, 64))
+    q, _ = np.linalg.qr(g)
+    alt = np.where(np.arange(64) % 2, 1.0, -1.0)
+    spectra = {
+        "geometric 1e-10..1, alternating": np.geomspace(1e-10, 1.0, 64) * alt,
+        "geometric 1e-6..1, all negative but one": -np.geomspace(1e-6, 1.0, 64) * np.where(np.arange(64) == 63, -1.0, 1.0),
+        "rank 32 (exact zeros)": np.concatenate([np.zeros(32), np.linspace(-1.0, 1.0, 32)]),
+        "negative definite": -np.linspace(0.1, 1.0, 64),
+        "-0.3 I": -0.3 * np.ones(64),
+        "one dominant eigenvalue, bulk +-1e-7": np.concatenate([[1.0], 1e-7 * alt[1:]]),
+        "clustered at +-1e-3": 1e-3 * alt * (1 + 1e-9 * np.arange(64)),
+    }
+    mats = []
+    for ev in spectra.values():
+        a = (q * ev) @ q.conj().T
+        mats.append((a + a.conj().T) / 2)
+    mats.append(np.zeros((64, 64), dtype=np.complex128))
+    batch = np.stack(mats)
+    eng = qp.get_engine(3)
+    got, steps = eng.cptp_project(batch, mode="cp", return_iters=True)
+    for name, a, r, st in zip(list(spectra) + ["zero matrix"], batch, got, steps):
+        w, u = np.linalg.eigh(a)
+        want = (u * np.maximum(w, 1e-12)) @ u.conj().T
+        scale = max(np.linalg.norm(a), 1e-12)
+        assert np.abs(r - want).max() < 2e-12 * max(scale, 1.0) + 1e-12, (name, np.abs(r - want).max(), int(st))
+        assert np.abs(r - r.conj().T).max() == 0.0, name  # exactly Hermitian
+        assert int(st) <= 40, (name, int(st))

@@ -621,18 +621,40 @@ def main():
         pb = 1024
         pc = torch.from_numpy(np.ascontiguousarray(np.stack([ptm.results] * pb))).cuda()
         pout = torch.empty((pb, 16, 16), dtype=torch.complex128, device="cuda")
+        choi_bytes = 16 * 36 * 8 + 16 * 16 * 16  # per process: int64 counts in, complex128 Choi matrix out
         for cptp in (False, True):
             ms = timed(lambda: peng.lifp_dev(pc, pout, cptp=cptp), 5, peng)
-            gemm_flop = 2.0 * pb * (16 * 36) * (2 * 256)  # [B x R] . [R x 2 D^2] on v_mfma_f64_16x16x4_f64, R = 16 x 36 rows
-            tf = gemm_flop / (ms * 1e-3) / 1e12
+            gbs = pb * choi_bytes / (ms * 1e-3) / 1e9
             others["configs[2] lifp" + (" + CPTP projection" if cptp else "")] = {
                 "batch": pb, "ms_per_launch": round(ms, 4), "value": round(pb / ms * 1e3, 1), "unit": "Choi reconstructions/s",
-                "mfma": {"gemm_flop": gemm_flop, "tflops_over_the_whole_call": round(tf, 2),
-                         "frac_of_peak": round(tf / FP64_PEAK_TFLOPS, 4),
-                         "frac_of_measured_ceiling": round(tf / FP64_MFMA_MEASURED_TFLOPS, 4),
-                         "note": ("the call = k_lifp_freq + k_lifp_gemm" + (" + k_cptp_project (Dykstra; its sign-function products "
-                                  "are MFMA work too, not counted here)" if cptp else "") +
-                                  "; the GEMM kernel alone: profiles/round3_*kernel_stats*")}}
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_process": choi_bytes,
+                             "note": ("k_lifp16: one wavefront per process through the Kronecker factors of the left inverse, 34 "
+                                      "v_mfma_f64_16x16x4_f64 per process (the dense operator costs 288)" +
+                                      (" + k_cptp_project (Dykstra; bound by its sign iteration, not by HBM)" if cptp else ""))}}
+        # the same streaming kernel at a batch that fills the chip, and the dense-operator path (frequencies + FP64 GEMM
+        # against the 576 x 256 complex left inverse: what POVMs with M % 4 != 0 take) beside it
+        pbig = 65536  # 302 MB of counts in, 268 MB of Choi matrices out per launch: beyond L2 (32 MB) and the 256 MB Infinity Cache
+        pcb = pc.repeat(pbig // pb, 1, 1, 1).contiguous()
+        poutb = torch.empty((pbig, 16, 16), dtype=torch.complex128, device="cuda")
+        ms = timed(lambda: peng.lifp_dev(pcb, poutb, cptp=False), 5, peng)
+        gbs = pbig * choi_bytes / (ms * 1e-3) / 1e9
+        others["configs[2] lifp, saturated"] = {
+            "batch": pbig, "ms_per_launch": round(ms, 4), "value": round(pbig / ms * 1e3, 1), "unit": "Choi reconstructions/s",
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_process": choi_bytes}}
+        del pcb, poutb
+        peng.process_prefer_dense(True)
+        ms = timed(lambda: peng.lifp_dev(pc, pout, cptp=False), 5, peng)
+        peng.process_prefer_dense(False)
+        gemm_flop = 2.0 * pb * (16 * 36) * (2 * 256)  # [B x R] . [R x 2 D^2] on v_mfma_f64_16x16x4_f64, R = 16 x 36 rows
+        tf = gemm_flop / (ms * 1e-3) / 1e12
+        others["configs[2] lifp, dense-operator path"] = {
+            "batch": pb, "ms_per_launch": round(ms, 4), "value": round(pb / ms * 1e3, 1), "unit": "Choi reconstructions/s",
+            "mfma": {"gemm_flop": gemm_flop, "tflops_over_the_whole_call": round(tf, 2),
+                     "frac_of_peak": round(tf / FP64_PEAK_TFLOPS, 4),
+                     "frac_of_measured_ceiling": round(tf / FP64_MFMA_MEASURED_TFLOPS, 4),
+                     "note": "the call = k_lifp_freq + k_lifp_gemm; the GEMM kernel alone: profiles/round3_*kernel_stats*"}}
         del pc, pout
         # the same at n = 3 (not a BASELINE config; 64 x 216 rows, Kronecker-factored set-up, 64 x 64 CPTP projection)
         np.random.seed(31)

@@ -877,7 +877,7 @@ __global__ void k_vp_perm(const double* __restrict__ vp_pinvT, int M, int D, int
 }
 
 template <int KSC>
-__global__ void __launch_bounds__(256) k_lifp16(const int64_t* __restrict__ counts, int B, int M,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_lifp16(const int64_t* __restrict__ counts, int B, int M,
                                                 const double* __restrict__ vp_perm, const double* __restrict__ vs_pinv,
                                                 double* __restrict__ choi, int32_t* __restrict__ status,
                                                 int32_t* __restrict__ iters) {

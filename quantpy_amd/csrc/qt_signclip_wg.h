@@ -15,7 +15,13 @@
 // An eigenvalue that is still unlifted after 40 doublings is below 1e-12 ||A||_F; what it then contributes to the
 // result is wrong by at most its own size, so the cap costs nothing measurable and there is no failure mode that
 // needs a fallback.  Y is re-symmetrised when it is read (one extra LDS read), which keeps rounding from feeding
-// a non-Hermitian component.  Agreement with LAPACK-eigh clipping: ~1e-15 (tests/test_gpu_large.py).
+// a non-Hermitian component, and X is replaced by its Hermitian part every fourth step (round 3): X W is Hermitian only
+// up to rounding, and the rows of its anti-Hermitian part that belong to a still-unlifted eigen-direction are multiplied
+// by the lifting slope with everything else -- 1e-16 became 1e-4 over 40 doublings on an exactly rank-deficient matrix
+// (the linear-inversion estimate of a pure state from exact frequencies), and the clip ended 1e-9 from an eigh-based one
+// on such inputs while agreeing to 1e-15 on separated spectra (NumPy model of this loop: 8e-10 without, 5e-16 with the
+// symmetrisation, every step or every eighth alike; qt_process64.h has the 64 x 64 measurements on the GPU).
+// Agreement with LAPACK-eigh clipping: ~1e-15 (tests/test_gpu_large.py).
 //
 // Complex product C = A B on the matrix cores, THREE real products per tile (round 3): one wavefront per 16 x 16 tile of
 // C accumulates P1 = Ar Br, P2 = Ai Bi and P3 = (Ar + Ai)(Br + Bi) over K in steps of 4 (operand layout as k_gemm,
@@ -107,6 +113,14 @@ struct SignClipWG {
     return s;
   }
 
+  // X <- (X + X^dagger) / 2, one element per thread (e = i P + j, et = j P + i); starts behind a barrier, ends with one
+  __device__ __forceinline__ static void symmetrise(cd* X, int e, int et) {
+    const cd x = X[e], xt = X[et];
+    __syncthreads();
+    X[e] = cd{0.5 * (x.re + xt.re), 0.5 * (x.im - xt.im)};
+    __syncthreads();
+  }
+
   // C = A * B.  Ends with a barrier: C is visible to every thread, A and B may be overwritten.
   __device__ static void matmul(const cd* A, const cd* B, cd* C) {
     if constexpr (kThreeMult) {
@@ -151,7 +165,7 @@ struct SignClipWG {
   }
 
   // In: this thread's element of a Hermitian matrix.  Out: its element of U max(lambda, eps) U^dagger (/ trace).
-  __device__ static cd clip(const int t, cd a, const double eps, double* sm, const Lds o, const bool normalise) {
+  __device__ __forceinline__ static cd clip(const int t, cd a, const double eps, double* sm, const Lds o, const bool normalise) {
     const int i = t / d, j = t % d, e = i * P + j, et = j * P + i;
     const double dlt = (i == j) ? 1.0 : 0.0;
     double* red = sm + o.red;
@@ -229,6 +243,7 @@ struct SignClipWG {
         xo = wo;
         wo = tmp;
         if (last || !(res == res)) break;
+        if ((k & 3) == 3) symmetrise(reinterpret_cast<cd*>(sm + xo), e, et);  // (uniform)
       }
     } else {
       const int wave = (int)(threadIdx.x >> 6) - duty0(), lane = threadIdx.x & 63;
@@ -314,6 +329,7 @@ struct SignClipWG {
         xo = wo;
         wo = tmp;
         if (last || !(res == res)) break;
+        if ((k & 3) == 3) symmetrise(reinterpret_cast<cd*>(sm + xo), e, et);  // (uniform)
       }
     }
     QT_STAMP(27);

@@ -171,3 +171,34 @@ def test_born_probabilities_product_path(qp, oracle, n):
         assert got.shape == want.shape
         assert np.abs(got - want).max() < 1e-14, (n, povm_name)
         assert np.abs(got.sum(-1) - 1).max() < 1e-12
+
+
+@pytest.mark.parametrize("n", [4, 5])
+def test_lin_on_exact_frequencies_of_pure_states(qp, oracle, n):
+    """Exactly rank-deficient input to the eigenvalue clip: |0...0>, a GHZ state and a product of |+> and |0>, measured in
+    all Pauli product bases with 2^20 shots per setting and counts EQUAL to the probabilities times the shots (all
+    multiples of 2^-n), so the linear-inversion estimate is the pure state up to rounding and d - 1 eigenvalues are
+    +-1e-17.  The sign-function clip keeps every iterate Hermitian since round 3; before, the anti-Hermitian rounding of
+    X W grew with the lifting in exactly these null directions (qt_signclip_wg.h).  Against the oracle's eigh clip."""
+    d = 2**n
+    a = qp.generate_measurement_matrix("proj-set", n)
+    ad = np.array(a)
+    shots = 2**20
+    zero = np.zeros(d); zero[0] = 1.0
+    ghz = np.zeros(d); ghz[0] = ghz[-1] = 2**-0.5
+    plus0 = np.kron(np.full(2**(n - 2), 2.0**(-(n - 2) / 2)), np.eye(4)[0])
+    eng = qp.get_engine(n)
+    eng.set_povm(a, np.full(ad.shape[0], shots))
+    counts = []
+    for psi in (zero, ghz, plus0):
+        p = oracle.born_probs(ad, oracle.bloch_from_matrix(np.outer(psi, psi.conj())))
+        c = np.rint(p * shots)
+        assert np.abs(c - p * shots).max() < 1e-6  # the probabilities are dyadic: the counts are exact
+        counts.append(c.astype(np.int64))
+    counts = np.stack(counts)
+    got = eng.lin(counts)
+    for c, r, psi in zip(counts, got, (zero, ghz, plus0)):
+        want = oracle.lin_estimate(c, ad)
+        assert np.abs(r - want).max() < 1e-12, np.abs(r - want).max()
+        assert np.abs(r - np.outer(psi, psi.conj())).max() < 1e-10
+        assert np.abs(r - r.conj().T).max() < 1e-15 and np.linalg.eigvalsh(r).min() > -1e-15

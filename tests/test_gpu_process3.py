@@ -380,3 +380,27 @@ def test_n3_cp_step_on_hard_spectra():
         assert np.abs(r - want).max() < 2e-12 * max(scale, 1.0) + 1e-12, (name, np.abs(r - want).max(), int(st))
         assert np.abs(r - r.conj().T).max() == 0.0, name  # exactly Hermitian
         assert int(st) <= 40, (name, int(st))
+
+
+def test_n2_cp_step_on_rank_deficient_and_tiny_spectra():
+    """The 16 x 16 CP step (k_cptp_project<16>, SignClipWG<16>) on what test_n3_cp_step_on_hard_spectra gives the 64 x 64 one:
+    the Choi matrix of a unitary channel (rank one, exact zeros), eigenvalues down to 1e-10 of the norm with both signs."""
+    import quantpy_amd as qp
+
+    rng = np.random.default_rng(16)
+    g = rng.standard_normal((16, 16)) + 1j * rng.standard_normal((16, 16))
+    q, _ = np.linalg.qr(g)
+    alt = np.where(np.arange(16) % 2, 1.0, -1.0)
+    u4, _ = np.linalg.qr(rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4)))
+    v = u4.T.reshape(-1)
+    mats = [np.outer(v, v.conj())]  # Choi matrix of rho -> U rho U^dagger
+    for ev in (np.geomspace(1e-10, 1.0, 16) * alt, np.concatenate([np.zeros(8), np.linspace(-1.0, 1.0, 8)]),
+               np.concatenate([[1.0], 1e-7 * alt[1:]])):
+        a = (q * ev) @ q.conj().T
+        mats.append((a + a.conj().T) / 2)
+    batch = np.stack(mats)
+    got = qp.get_engine(2).cptp_project(batch, mode="cp")
+    for a, r in zip(batch, got):
+        w, u = np.linalg.eigh(a)
+        want = (u * np.maximum(w, 1e-12)) @ u.conj().T
+        assert np.abs(r - want).max() < 3e-12 * max(np.linalg.norm(a), 1.0) + 1e-12, np.abs(r - want).max()

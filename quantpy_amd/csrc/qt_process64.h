@@ -304,7 +304,14 @@ struct Proc64 {
         tile_product(Y, Y, wk, pz);
         __syncthreads();  // every wavefront has read Y
 #pragma unroll
-        for (int r = 0; r < EPT; ++r) pz[r] = cd{fma(1.25, pz[r].re, -3.25 * pr[r].re), fma(1.25, pz[r].im, -3.25 * pr[r].im)};
+        for (int t = 0; t < 2; ++t) {  // (Y's own tile re-read: cheaper than 16 registers alive through the product)
+          if (t == 1 && !wk.two) break;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const cd y = Y[(wk.row0 + wk.kq + 4 * r) * P + wk.col0 + 16 * t + wk.r16];
+            pz[4 * t + r] = cd{fma(1.25, pz[4 * t + r].re, -3.25 * y.re), fma(1.25, pz[4 * t + r].im, -3.25 * y.im)};
+          }
+        }
         (void)store_hermitian(Y, wk, pz);  // W' (its diagonal tiles symmetrised like Y's)
         __syncthreads();
         alpha = 3.0, beta = 1.0;

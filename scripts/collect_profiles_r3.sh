@@ -27,7 +27,11 @@ QT_BENCH_FORCE_DIST=1 timeout -k 10 600 python3 bench.py --no-cpu-baseline > $OU
 step "timing scripts"
 timeout -k 10 300 python3 scripts/headline_timing.py 500 > $OUT/${TAG}_headline_timing.txt 2>&1
 timeout -k 10 300 python3 scripts/iterating_timing.py > $OUT/${TAG}_iterating_timing.txt 2>&1
-timeout -k 10 300 python3 scripts/process_timing.py > $OUT/${TAG}_process_timing.txt 2>&1
+{ timeout -k 10 300 python3 scripts/process_timing.py 1024; timeout -k 10 300 python3 scripts/process_timing.py 16384; timeout -k 10 300 python3 scripts/process_timing.py 64; } > $OUT/${TAG}_process_timing.txt 2>&1
+{ timeout -k 10 300 python3 scripts/process_timing.py 64 3; timeout -k 10 300 python3 scripts/process_timing.py 256 3; timeout -k 10 300 python3 scripts/process_timing.py 1024 3; } > $OUT/${TAG}_process3_timing.txt 2>&1
+timeout -k 10 600 python3 scripts/pgdb3_timing.py > $OUT/${TAG}_pgdb3_timing.txt 2>&1
+{ timeout -k 10 300 python3 scripts/cp_hard_spectra.py; timeout -k 10 300 python3 scripts/cp_accuracy_probe.py; } > $OUT/${TAG}_cp_accuracy_n3.txt 2>&1
+timeout -k 10 600 python3 scripts/clip_accuracy_n5.py > $OUT/${TAG}_clip_accuracy_n5.txt 2>&1
 { timeout -k 10 300 python3 scripts/large_n_timing.py 5 256; timeout -k 10 300 python3 scripts/large_n_timing.py 5 2048; timeout -k 10 300 python3 scripts/large_n_timing.py 4 1024; } > $OUT/${TAG}_large_n_timing.txt 2>&1
 timeout -k 10 300 python3 scripts/moment_coverage_timing.py > $OUT/${TAG}_moment_coverage_timing.txt 2>&1
 timeout -k 10 300 python3 scripts/bootstrap_timing.py > $OUT/${TAG}_bootstrap_end_to_end.txt 2>&1
@@ -36,6 +40,7 @@ timeout -k 10 300 ./scripts/ubench/valu_f64_warm > $OUT/${TAG}_ubench_valu_f64_w
 timeout -k 10 300 ./scripts/ubench/mfma_f64_warm > $OUT/${TAG}_ubench_mfma_f64_warm.txt 2>&1
 step "phase stamps (profile build)"
 QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing_large.py 5 256 > $OUT/${TAG}_phase_timing_n5.txt 2>&1
+{ QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing_large_bfgs.py 5 256; QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing_large_bfgs.py 4 1024; } > $OUT/${TAG}_phase_timing_large_bfgs.txt 2>&1
 { QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing_cptp.py 1024; QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing_cptp.py 256; } > $OUT/${TAG}_phase_timing_cptp.txt 2>&1
 QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/phase_timing.py > $OUT/${TAG}_phase_timing_B1000.txt 2>&1
 QTOMO_LIB=quantpy_amd/lib/libqtomo_prof.so timeout -k 10 300 python3 scripts/gemm_diag.py > $OUT/${TAG}_gemm_phase_switches.txt 2>&1

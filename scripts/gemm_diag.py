@@ -15,6 +15,7 @@ np.random.seed(11)
 ptm = qp.ProcessTomograph(qp.channel.depolarizing(0.1, 2))
 ptm.experiment(10000, "proj-set")
 eng = ptm._engine()
+eng.process_prefer_dense(True)  # (the dense-operator path: qt_lifp_batch otherwise multiplies by the Kronecker factors, k_lifp16)
 pc = torch.from_numpy(np.ascontiguousarray(np.stack([ptm.results] * B))).cuda()
 out = torch.empty((B, 16, 16), dtype=torch.complex128, device="cuda")
 for diag in (0, 8, 4, 2, 1, 3, 7, 15, 0):  # (the variants the profile build instantiates)

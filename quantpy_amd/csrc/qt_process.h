@@ -892,14 +892,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
   const int KS = KSC > 0 ? KSC : (M >> 2);
   const double* bp = s_vp + kq * 32 + r16;
   const v4f64 z = {0.0, 0.0, 0.0, 0.0};
-  for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {  // (wave-uniform)
+  const int stride = gridDim.x * 4;
+  long long nx[KSC > 0 ? KSC : 1];  // the NEXT process's counts: requested before this one's products start
+  if constexpr (KSC > 0) {
+    const int b0 = blockIdx.x * 4 + w;
+    if (b0 < B) {
+      const int64_t* c0 = counts + ((size_t)b0 * DC + r16) * M + kq;
+#pragma unroll
+      for (int k = 0; k < KSC; ++k) nx[k] = c0[4 * k];
+    }
+  }
+  for (int b = blockIdx.x * 4 + w; b < B; b += stride) {  // (wave-uniform)
     const int64_t* crow = counts + ((size_t)b * DC + r16) * M + kq;
     v4f64 tre[2] = {z, z}, tim[2] = {z, z};
     double rs = 0.0;
     if constexpr (KSC > 0) {
       long long n[KSC];
 #pragma unroll
-      for (int k = 0; k < KSC; ++k) n[k] = crow[4 * k];
+      for (int k = 0; k < KSC; ++k) n[k] = nx[k];
+      if (b + stride < B) {
+        const int64_t* cn = crow + (size_t)stride * DC * M;
+#pragma unroll
+        for (int k = 0; k < KSC; ++k) nx[k] = cn[4 * k];
+      }
 #pragma unroll
       for (int k = 0; k < KSC; ++k) {
         const double dn = (double)n[k];

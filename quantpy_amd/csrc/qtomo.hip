@@ -1725,7 +1725,8 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
       raw = h->ws_g.as<double>();
     }
     int grid = (B + 3) / 4;
-    if (grid > 4096) grid = 4096;  // (16 workgroups per CU; the wavefronts stride over the batch)
+    if (grid > 768) grid = 768;  // three resident workgroups per CU (166 VGPRs): the wavefronts stride over the batch with the
+                                 // next process's counts in flight, and a workgroup stages V_P^+ once for all its processes
     const size_t lds = (size_t)M * 32 * sizeof(double);
     int32_t *st = cptp ? (int32_t*)nullptr : dst, *it0 = cptp ? (int32_t*)nullptr : dit;
     if (M == 36)

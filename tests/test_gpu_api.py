@@ -277,10 +277,10 @@ def test_lifp_batched_gemm_path_matches_fused_kernel_and_oracle(qp, oracle):
     assert np.abs(eng.lifp(counts2, cptp=False) - big).max() < 1e-11
     # more processes than resident wavefronts (the grid is capped: wavefronts stride over the batch), and the factors
     # themselves: entry [(c d + e) D + (a d + b)][s M + m] of the dense left inverse is V_S^+[a d + c][s] V_P^+[e d + b][m]
-    b3 = 16384 + 37
+    b3 = 4 * 768 * 3 + 37
     counts3 = rng.multinomial(5000, np.full(4, 0.25), size=(b3, 16, nset)).astype(np.int64)
     many = eng.lifp(counts3, cptp=False)
-    assert np.array_equal(many[[0, 4096 * 4, b3 - 1]], eng.lifp(counts3[[0, 4096 * 4, b3 - 1]], cptp=False))
+    assert np.array_equal(many[[0, 768 * 4, b3 - 1]], eng.lifp(counts3[[0, 768 * 4, b3 - 1]], cptp=False))
     assert np.isfinite(many).all()
     vs, vp = eng.process_factors()
     _, inv = eng.process_operators()

@@ -923,7 +923,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
         tim[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(dn, bp[k * 128 + 16], tim[k & 1], 0, 0, 0);
       }
     } else {
-#pragma unroll 4
       for (int k = 0; k < KS; ++k) {
         const double dn = (double)crow[4 * k];
         rs += dn;

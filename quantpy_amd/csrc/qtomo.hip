@@ -17,6 +17,7 @@
 #include "qt_ops.h"
 #include "qt_process.h"
 #include "qt_process64.h"
+#include "qt_process_wave16.h"
 #include "qt_sampler.h"
 #include "qt_small.h"
 
@@ -1736,8 +1737,8 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
       hipLaunchKernelGGL(qt::k_lifp16<0>, dim3(grid), dim3(256), lds, h->stream, dc, B, M, (const double*)h->proc.vp_perm,
                          (const double*)h->proc.vs_pinv, raw, st, it0);
     if (cptp)
-      hipLaunchKernelGGL(qt::k_cptp_project<16>, dim3(B), dim3(qt::ProcWG<16>::NT), 0, h->stream, (const double*)raw, B, 0,
-                         1000, 1e-12, dchoi, dit, dst);
+      hipLaunchKernelGGL(qt::k_cptp_wave16, dim3((B + 3) / 4), dim3(256), 0, h->stream, (const double*)raw, B, 0, 1000, 1e-12,
+                         dchoi, dit, dst);
   } else if (B >= 256 && gemm_lds <= 152 * 1024) {
     // many processes: frequencies, then one FP64 MFMA GEMM over the batch, then (cptp) the projection kernel
     constexpr int NE = 256;
@@ -1780,8 +1781,8 @@ int qt_lifp_batch(qt_handle_t* h, const int64_t* counts, int B, int cptp, double
                          (const double*)h->proc.pinvR, raw, cptp ? (int32_t*)nullptr : dst, cptp ? (int32_t*)nullptr : dit);
     }
     if (cptp)
-      hipLaunchKernelGGL(qt::k_cptp_project<16>, dim3(B), dim3(qt::ProcWG<16>::NT), 0, h->stream, (const double*)raw, B, 0,
-                         1000, 1e-12, dchoi, dit, dst);
+      hipLaunchKernelGGL(qt::k_cptp_wave16, dim3((B + 3) / 4), dim3(256), 0, h->stream, (const double*)raw, B, 0, 1000, 1e-12,
+                         dchoi, dit, dst);
   } else {
     hipLaunchKernelGGL(qt::k_lifp_batch<16>, dim3(B), dim3(qt::ProcWG<16>::NT), dyn, h->stream, dc, B, M,
                        (const double*)h->proc.pinvT, cptp, dchoi, dit, dst);
@@ -1984,8 +1985,8 @@ int qt_cptp_project_batch(qt_handle_t* h, const double* choi_in, int B, int mode
     hipLaunchKernelGGL(qt::k_cptp_project<4>, dim3(B), dim3(qt::ProcWG<4>::NT), 0, h->stream, din, B, mode, n_iter, tol, dout,
                        dit);
   else
-    hipLaunchKernelGGL(qt::k_cptp_project<16>, dim3(B), dim3(qt::ProcWG<16>::NT), 0, h->stream, din, B, mode, n_iter, tol,
-                       dout, dit);
+    hipLaunchKernelGGL(qt::k_cptp_wave16, dim3((B + 3) / 4), dim3(256), 0, h->stream, din, B, mode, n_iter, tol, dout, dit,
+                       (int32_t*)nullptr);
   if (int r = fetch_out(h, dout, choi_out, (size_t)B * D * D * 2, flags)) return r;
   if (int r = fetch_out(h, dit, iters, (size_t)B, flags)) return r;
   return finish(h, flags);

@@ -36,9 +36,9 @@ for mode, name in ((2, "one CP step"), (0, "Dykstra CPTP")):
     eng.timer_begin()
     eng._chk(eng.lib.qt_cptp_project_batch(eng._h, _ptr(x), B, mode, 1000, 1e-12, _ptr(out), _ptr(iters), _capi.QT_DEVICE_PTR))
     ms = eng.timer_end()
-    p = prof.cpu().numpy()[: B * 4: 4]
+    p = prof.cpu().numpy()[:B]  # (k_cptp_wave16: one wavefront = one row of stamps per matrix)
     tot = p[:, 1] - p[:, 0]
-    print(f"== {name}: {ms * 1e3:.1f} us for {B} matrices; kernel clocks per workgroup mean {tot.mean():.0f} max {tot.max()}; "
+    print(f"== {name}: {ms * 1e3:.1f} us for {B} matrices; kernel clocks per wavefront (= matrix) mean {tot.mean():.0f} max {tot.max()}; "
           f"iterations {int(iters[0])}")
     print(f"   last projection of the run: PD test ends {np.mean(p[:, 2] - p[:, 0]):.0f} clk after entry (mode 2) ; sign loop "
           f"{np.mean(p[:, 27] - p[:, 26]):.0f} clk for {p[:, 25].mean():.1f} steps = {np.mean((p[:, 27] - p[:, 26]) / np.maximum(p[:, 25], 1)):.0f} clk/step ; "

@@ -631,7 +631,8 @@ def main():
                              "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_process": choi_bytes,
                              "note": ("k_lifp16: one wavefront per process through the Kronecker factors of the left inverse, 34 "
                                       "v_mfma_f64_16x16x4_f64 per process (the dense operator costs 288)" +
-                                      (" + k_cptp_project (Dykstra; bound by its sign iteration, not by HBM)" if cptp else ""))}}
+                                      (" + k_cptp_wave16 (Dykstra with one wavefront per process; bound by the matrix instructions of its sign iteration, "
+                                       "not by HBM)" if cptp else ""))}}
         # the same streaming kernel at a batch that fills the chip, and the dense-operator path (frequencies + FP64 GEMM
         # against the 576 x 256 complex left inverse: what POVMs with M % 4 != 0 take) beside it
         pbig = 65536  # 302 MB of counts in, 268 MB of Choi matrices out per launch: beyond L2 (32 MB) and the 256 MB Infinity Cache

@@ -30,6 +30,7 @@ timeout -k 10 300 python3 scripts/iterating_timing.py > $OUT/${TAG}_iterating_ti
 { timeout -k 10 300 python3 scripts/process_timing.py 1024; timeout -k 10 300 python3 scripts/process_timing.py 16384; timeout -k 10 300 python3 scripts/process_timing.py 64; } > $OUT/${TAG}_process_timing.txt 2>&1
 { timeout -k 10 300 python3 scripts/process_timing.py 64 3; timeout -k 10 300 python3 scripts/process_timing.py 256 3; timeout -k 10 300 python3 scripts/process_timing.py 1024 3; } > $OUT/${TAG}_process3_timing.txt 2>&1
 timeout -k 10 600 python3 scripts/pgdb3_timing.py > $OUT/${TAG}_pgdb3_timing.txt 2>&1
+timeout -k 10 300 python3 scripts/lifp16_stream_timing.py > $OUT/${TAG}_lifp16_stream_timing.txt 2>&1
 { timeout -k 10 300 python3 scripts/cp_hard_spectra.py; timeout -k 10 300 python3 scripts/cp_accuracy_probe.py; } > $OUT/${TAG}_cp_accuracy_n3.txt 2>&1
 timeout -k 10 600 python3 scripts/clip_accuracy_n5.py > $OUT/${TAG}_clip_accuracy_n5.txt 2>&1
 { timeout -k 10 300 python3 scripts/large_n_timing.py 5 256; timeout -k 10 300 python3 scripts/large_n_timing.py 5 2048; timeout -k 10 300 python3 scripts/large_n_timing.py 4 1024; } > $OUT/${TAG}_large_n_timing.txt 2>&1

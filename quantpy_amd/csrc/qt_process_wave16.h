@@ -107,9 +107,10 @@ struct ProcWave16 {
   }
 
   // Cholesky test: every pivot above eps <=> the clip at eps is the identity (to within eps).  Right-looking elimination
-  // on the full Hermitian matrix: the trailing block lives in registers and, for the column / row reads of the next step,
-  // in the wavefront's LDS scratch (a rolled loop: unrolled, with column k travelling by shuffles, the kernel needed 248
-  // registers).
+  // on the full Hermitian matrix: the trailing block lives in registers and, for the column / row reads of the next round,
+  // in the wavefront's LDS scratch (a rolled loop: unrolled, with the columns travelling by shuffles, the kernel needed 248
+  // registers).  TWO columns per round trip: column and row k + 1 are read as they are and take column k's update locally --
+  // the same operations in the same order as one column at a time, so the same bits, in 8 LDS round trips instead of 16.
   __device__ __forceinline__ static bool is_pd(const Lane& L, const cd (&a)[4], double eps) {
     cd w[4];
     wave_sync();
@@ -118,24 +119,40 @@ struct ProcWave16 {
       w[r] = a[r];
       L.T[L.i(r) * PT + L.r16] = a[r];
     }
-    for (int k = 0; k < DC; ++k) {
-      wave_sync();  // the stores of the step before are in the scratch
-      const double piv = L.T[k * PT + k].re;
-      if (!(piv > eps)) return false;  // uniform: every lane reads the same pivot
-      const double inv = 1.0 / piv;
-      const cd rk = L.T[k * PT + L.r16];  // a[k][j]
+    for (int k = 0; k < DC; k += 2) {
+      wave_sync();  // the stores of the round before are in the scratch
+      const double piv0 = L.T[k * PT + k].re;
+      const cd akk1 = L.T[k * PT + k + 1], ak1k = L.T[(k + 1) * PT + k];  // a[k][k+1], a[k+1][k]
+      const double d1 = L.T[(k + 1) * PT + k + 1].re;
+      const cd r0 = L.T[k * PT + L.r16], r1 = L.T[(k + 1) * PT + L.r16];  // a[k][j], a[k+1][j]
+      cd c0[4], c1[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const cd ci = L.T[L.i(r) * PT + k];  // a[i][k]
-        if (L.i(r) > k && L.r16 > k) {
-          w[r].re -= (ci.re * rk.re - ci.im * rk.im) * inv;  // a_ik a_kj / a_kk  (a_kj = conj(a_jk))
-          w[r].im -= (ci.re * rk.im + ci.im * rk.re) * inv;
+        c0[r] = L.T[L.i(r) * PT + k];  // a[i][k]
+        c1[r] = L.T[L.i(r) * PT + k + 1];
+      }
+      if (!(piv0 > eps)) return false;  // uniform: every lane reads the same pivots
+      const double inv0 = 1.0 / piv0;
+      // column k out of row k + 1, column k + 1 and the second pivot -- what one column at a time would have stored
+      const double piv1 = d1 - (ak1k.re * akk1.re - ak1k.im * akk1.im) * inv0;
+      if (!(piv1 > eps)) return false;
+      const double inv1 = 1.0 / piv1;
+      const cd r1u{r1.re - (ak1k.re * r0.re - ak1k.im * r0.im) * inv0, r1.im - (ak1k.re * r0.im + ak1k.im * r0.re) * inv0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (L.i(r) > k + 1 && L.r16 > k + 1) {
+          const cd c1u{c1[r].re - (c0[r].re * akk1.re - c0[r].im * akk1.im) * inv0,
+                       c1[r].im - (c0[r].re * akk1.im + c0[r].im * akk1.re) * inv0};
+          w[r].re -= (c0[r].re * r0.re - c0[r].im * r0.im) * inv0;  // a_ik a_kj / a_kk  (a_kj = conj(a_jk))
+          w[r].im -= (c0[r].re * r0.im + c0[r].im * r0.re) * inv0;
+          w[r].re -= (c1u.re * r1u.re - c1u.im * r1u.im) * inv1;
+          w[r].im -= (c1u.re * r1u.im + c1u.im * r1u.re) * inv1;
         }
       }
-      wave_sync();  // every lane has read column and row k
+      wave_sync();  // every lane has read its columns and rows
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (L.i(r) > k && L.r16 > k) L.T[L.i(r) * PT + L.r16] = w[r];
+        if (L.i(r) > k + 1 && L.r16 > k + 1) L.T[L.i(r) * PT + L.r16] = w[r];
     }
     return true;
   }

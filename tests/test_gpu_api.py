@@ -314,3 +314,36 @@ def test_lifp_batched_ragged_povm_and_nan_isolation(qp):
     keep = np.arange(b) != 137
     assert np.isfinite(big[keep]).all()
     assert np.abs(big[keep] - ref[keep]).max() < 1e-12
+
+
+@pytest.mark.parametrize("pieces", [1, 5, 13])
+def test_lifp_factor_kernel_generic_row_counts(qp, oracle, pieces):
+    """k_lifp16 with M / 4 not the compile-time 9 of the 'proj-set' POVM: all 36 'proj-set' elements as ONE measurement
+    (each / 9) with the last one split into `pieces` equal parts -- M = 36 (the specialised kernel), 40 and 48 (the
+    run-time loop) -- against the dense-operator path of the same set-up and the factor formula in NumPy."""
+    np.random.seed(17)
+    tmg = qp.ProcessTomograph(qp.channel.depolarizing(0.2, 2))
+    rows = np.asarray(qp.generate_measurement_matrix("proj-set", 2), dtype=np.float64).reshape(-1, 16) / 9.0
+    rows = np.concatenate([rows[:-1]] + [rows[-1:] / pieces] * pieces)
+    m = rows.shape[0]
+    assert m == 35 + pieces and m % 4 == 0
+    eng = qp.get_engine(2)
+    eng.set_povm(rows[None], 9 * 4000)
+    eng.process_setup(np.stack([np.asarray(s.matrix, dtype=np.complex128) for s in tmg.input_basis.elements]))
+    rng = np.random.default_rng(pieces)
+    b = 333
+    counts = rng.integers(0, 3000, size=(b, 16, 1, m)).astype(np.int64)
+    fac = eng.lifp(counts, cptp=False)
+    eng.process_prefer_dense(True)
+    dense = eng.lifp(counts, cptp=False)
+    eng.process_prefer_dense(False)
+    assert np.abs(fac - dense).max() < 1e-10 * np.abs(dense).max()
+    vs, vp = eng.process_factors()
+    d = 4
+    a_, b_, c_, e_ = np.meshgrid(np.arange(d), np.arange(d), np.arange(d), np.arange(d), indexing="ij")
+    for k in (0, b - 1):
+        f = counts[k, :, 0, :] / counts[k, :, 0, :].sum(axis=1, keepdims=True)
+        x = vs @ f @ vp.T
+        want = np.empty((16, 16), dtype=np.complex128)
+        want[(a_ * d + b_).ravel(), (c_ * d + e_).ravel()] = x[(a_ * d + c_).ravel(), (e_ * d + b_).ravel()]
+        assert np.abs(fac[k] - want).max() < 1e-11 * max(1.0, np.abs(want).max())

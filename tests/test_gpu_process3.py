@@ -132,14 +132,17 @@ def test_n3_process_without_counts_is_nan_and_alone(g3):
     assert iters[0] == int(g3["Q0_dykstra_iters"]) and iters[2] == int(g3["Q1_dykstra_iters"])
 
 
-def test_n3_cptp_projection_regimes_against_eigh_dykstra(oracle):
-    """k_cptp_project64 on Choi matrices the fixtures do not reach -- already CPTP, CP but not TP, TP but far from CP,
+@pytest.mark.parametrize("nq", [3, 2])
+def test_cptp_projection_regimes_against_eigh_dykstra(oracle, nq):
+    """k_cptp_project64 (n = 3) and k_cptp_wave16 (n = 2: one wavefront per process, the matrix in the registers of the
+    matrix-core tile) on Choi matrices the fixtures do not reach -- already CPTP, CP but not TP, TP but far from CP,
     a unitary channel (rank one) with noise, large noise -- against a NumPy Dykstra loop with eigh (process.py:237-278;
     its TP step checked once against the oracle's operator form): same iteration counts, Choi to 1e-9."""
     import quantpy_amd as qp
 
-    d, dc = 8, 64
-    rng = np.random.default_rng(64)
+    d = 2**nq
+    dc = d * d
+    rng = np.random.default_rng(dc)
     eye_d = np.eye(d)
 
     def tp(c):
@@ -181,15 +184,15 @@ def test_n3_cptp_projection_regimes_against_eigh_dykstra(oracle):
     base = random_cptp(3)
     assert np.abs(np.einsum("aobo->ab", base.reshape(d, d, d, d)) - eye_d).max() < 1e-12  # the construction is TP in this layout
     some = herm(0.05)
-    assert np.abs(tp(some) - oracle.vec2mat(oracle.tp_projection_vec(oracle.mat2vec(some), 3))).max() < 1e-12
+    assert np.abs(tp(some) - oracle.vec2mat(oracle.tp_projection_vec(oracle.mat2vec(some), nq))).max() < 1e-12
     cases = {
-        "already CPTP": random_cptp(64),
-        "CP, not TP": 1.3 * random_cptp(8),
+        "already CPTP": random_cptp(dc),
+        "CP, not TP": 1.3 * random_cptp(d),
         "unitary channel + noise": random_cptp(1) + herm(0.01),
         "rank 3 + large noise": base + herm(0.2),
         "indefinite": herm(1.0),
     }
-    eng = qp.get_engine(3)
+    eng = qp.get_engine(nq)
     batch = np.stack(list(cases.values()))
     got, iters = eng.cptp_project(batch, mode="cptp", return_iters=True)
     for (name, c), g, it in zip(cases.items(), got, iters):

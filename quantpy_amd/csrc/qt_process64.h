@@ -36,7 +36,8 @@ struct Proc64 {
   static constexpr int DC = 64, DQ = 8, NT = 512, NW = NT / 64, EPT = 8, P = DC + 1;
   // LDS layout, offsets in doubles (all even: cd accesses are 16-byte aligned)
   static constexpr int oImg0 = 0, oImg1 = oImg0 + 2 * DC * P, oCol = oImg1 + 2 * DC * P, oTp = oCol + 2 * 2 * DC,
-                       oRed = oTp + 2 * DC, oRed6 = oRed + 32, kDoubles = oRed6 + 6 * NW;
+                       oRed = oTp + 2 * DC, oRed6 = oRed + 32, oPart = oRed6 + 6 * NW + ((6 * NW) & 1),
+                       kDoubles = oPart + 2 * 4 * 64 * 2;  // oPart: the halves of the two split tiles (below), [tile][r][lane] complex
   static constexpr size_t kLdsBytes = (size_t)kDoubles * sizeof(double);
   static constexpr int kWsComplex = 5 * EPT * NT;  // global workspace per process: p, q, y, x, the clip's parked input
 
@@ -61,54 +62,67 @@ struct Proc64 {
     return s;
   }
 
-  // Y = X X and the final A S are Hermitian products, so only the 10 tiles on and above the diagonal of the 4 x 4 tile
-  // grid are computed and the 6 below are written as their mirror images.  Which wavefront computes what is decoupled
-  // there from which thread owns which element: wavefronts 0, 1 take two tiles each (row 0), the other six one each,
-  // i.e. 3 + 3 + 2 + 2 tiles on the four SIMDs (wavefronts w and w + 4 share one) instead of 4 each.
-  // Since round 3 X' = X W is computed the same way (round 2 computed it in full, each wavefront its own two tiles,
-  // because mirroring it had cost four digits: clip() below has what was wrong with that mirror, and with not mirroring).
+  // Every product of the CP step is Hermitian (Y = X X, Z = Y Y, X W, the final A S), so only the 10 tiles on and above the
+  // diagonal of the 4 x 4 tile grid are computed and the 6 below are written as their mirror images (clip() below has why
+  // the new X may be mirrored too, and what was wrong with round 2's mirror).  Which wavefront computes what is decoupled
+  // from which thread owns which element.  Ten tiles on four matrix pipes: every wavefront takes ONE tile over the whole
+  // K range, and the two tiles left over -- (0, 2) and (1, 3) -- are split in K between wavefronts 0 | 1 and 2 | 3, one half per
+  // SIMD (wavefronts w and w + 4 share a SIMD): 2.5 tiles per SIMD and product where rounds 2-3a had 3 + 3 + 2 + 2.  The first
+  // halves travel through 8 KB of LDS (`oPart`) to wavefronts 1 and 3, which add them and store the tile; the barrier that
+  // publishes them is the one that ends the operand reads anyway (product() below).
   struct Work {
-    int row0, col0, r16, kq;
-    bool two;  // a second tile at col0 + 16
+    int row0, col0, r16, kq, wave;
+    int hrow0, hcol0, kh0;  // the split tile and this wavefront's half of its K range (wavefronts 0..3)
+    bool half, owner;
     __device__ explicit Work(int tid) {
-      const int w = tid >> 6, lane = tid & 63;
-      row0 = 16 * ((0xE950 >> (2 * w)) & 3);  // tile rows    0 0 1 1 1 2 2 3
-      col0 = 16 * ((0xFB98 >> (2 * w)) & 3);  // tile columns 0 2 1 2 3 2 3 3
-      two = w < 2;
+      wave = tid >> 6;
+      const int lane = tid & 63;
+      row0 = 16 * ((0x3A50 >> (2 * wave)) & 3);  // tile rows    0 0 1 1 2 2 3 0
+      col0 = 16 * ((0xFE94 >> (2 * wave)) & 3);  // tile columns 0 1 1 2 2 3 3 3
+      half = wave < 4;
+      owner = half && (wave & 1);  // (wavefronts 1 and 3: their own tiles are off the diagonal -- no symmetrisation round trip)
+      hrow0 = 16 * (wave >> 1), hcol0 = 16 * (2 + (wave >> 1));  // (0, 2) for wavefronts 0 | 1, (1, 3) for 2 | 3
+      kh0 = 32 * (wave & 1);
       r16 = lane & 15, kq = lane >> 4;
     }
   };
 
-  // tile(s) (row0, col0 [, col0 + 16]) of A B into registers (c[0..3]: first tile, c[4..7]: second); no barrier inside.
-  // THREE real products per complex tile (round 3, as SignClipWG::tile_product at d = 32): P1 = Ar Br, P2 = Ai Bi,
-  // P3 = (Ar + Ai)(Br + Bi), C = (P1 - P2) + i (P3 - P1 - P2) -- the step is bound by the throughput of the FP64 matrix
-  // pipe (448 v_mfma_f64_16x16x4_f64 per SIMD and step with four products, 336 with three), and the three (six with two
-  // tiles) accumulator chains are independent.
-  __device__ __forceinline__ static void tiles(const cd* A, const cd* B, int row0, int col0, bool two, int r16, int kq,
-                                               cd (&c)[EPT]) {
+  // This wavefront's share of A B into registers: c[0..3] its tile, c[4..7] its half of a split tile (wavefronts 0..3); no
+  // barrier inside.  THREE real products per complex tile (round 3, as SignClipWG::tile_product at d = 32): P1 = Ar Br,
+  // P2 = Ai Bi, P3 = (Ar + Ai)(Br + Bi), C = (P1 - P2) + i (P3 - P1 - P2) -- the step is bound by the throughput of the FP64
+  // matrix pipe, and the three (six) accumulator chains are independent.
+  __device__ __forceinline__ static void tiles(const cd* A, const cd* B, const Work& wk, cd (&c)[EPT]) {
     const sc_v4f64 z = {0.0, 0.0, 0.0, 0.0};
     sc_v4f64 p1a = z, p2a = z, p3a = z, p1b = z, p2b = z, p3b = z;
-    const cd* ap = A + (row0 + r16) * P + kq;
-    const cd* bp = B + kq * P + col0 + r16;
-    if (two) {  // wave-uniform
+    const cd* ap = A + (wk.row0 + wk.r16) * P + wk.kq;
+    const cd* bp = B + wk.kq * P + wk.col0 + wk.r16;
+    if (wk.half) {  // wave-uniform
+      const cd* hp = A + (wk.hrow0 + wk.r16) * P + wk.kq + wk.kh0;
+      const cd* gp = B + (wk.kq + wk.kh0) * P + wk.hcol0 + wk.r16;
 #pragma unroll 4
-      for (int k0 = 0; k0 < DC; k0 += 4) {
-        const cd a = ap[k0], b0 = bp[k0 * P], b1 = bp[k0 * P + 16];
-        const double as = a.re + a.im;
-        p1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, p1a, 0, 0, 0);
-        p1b = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b1.re, p1b, 0, 0, 0);
-        p2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.im, p2a, 0, 0, 0);
-        p2b = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b1.im, p2b, 0, 0, 0);
-        p3a = __builtin_amdgcn_mfma_f64_16x16x4f64(as, b0.re + b0.im, p3a, 0, 0, 0);
-        p3b = __builtin_amdgcn_mfma_f64_16x16x4f64(as, b1.re + b1.im, p3b, 0, 0, 0);
+      for (int k0 = 0; k0 < DC / 2; k0 += 4) {  // the split tile's half beside the first half of the own tile: six chains
+        const cd a = ap[k0], b = bp[k0 * P], ha = hp[k0], hb = gp[k0 * P];
+        p1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, p1a, 0, 0, 0);
+        p1b = __builtin_amdgcn_mfma_f64_16x16x4f64(ha.re, hb.re, p1b, 0, 0, 0);
+        p2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.im, p2a, 0, 0, 0);
+        p2b = __builtin_amdgcn_mfma_f64_16x16x4f64(ha.im, hb.im, p2b, 0, 0, 0);
+        p3a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, b.re + b.im, p3a, 0, 0, 0);
+        p3b = __builtin_amdgcn_mfma_f64_16x16x4f64(ha.re + ha.im, hb.re + hb.im, p3b, 0, 0, 0);
+      }
+#pragma unroll 4
+      for (int k0 = DC / 2; k0 < DC; k0 += 4) {
+        const cd a = ap[k0], b = bp[k0 * P];
+        p1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, p1a, 0, 0, 0);
+        p2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.im, p2a, 0, 0, 0);
+        p3a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, b.re + b.im, p3a, 0, 0, 0);
       }
     } else {
 #pragma unroll 4
       for (int k0 = 0; k0 < DC; k0 += 4) {
-        const cd a = ap[k0], b0 = bp[k0 * P];
-        p1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b0.re, p1a, 0, 0, 0);
-        p2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b0.im, p2a, 0, 0, 0);
-        p3a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, b0.re + b0.im, p3a, 0, 0, 0);
+        const cd a = ap[k0], b = bp[k0 * P];
+        p1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, p1a, 0, 0, 0);
+        p2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.im, p2a, 0, 0, 0);
+        p3a = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, b.re + b.im, p3a, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -117,61 +131,64 @@ struct Proc64 {
       c[4 + r] = cd{p1b[r] - p2b[r], p3b[r] - p1b[r] - p2b[r]};
     }
   }
-  // the Hermitian products: this wavefront's share of the upper tiles
-  __device__ __forceinline__ static void tile_product(const cd* A, const cd* B, const Work& wk, cd (&c)[EPT]) {
-    tiles(A, B, wk.row0, wk.col0, wk.two, wk.r16, wk.kq, c);
-  }
 
-  // the computed tile(s) into image D, and their conjugate transposes into the mirror positions below the diagonal
-  __device__ __forceinline__ static void store_tiles(cd* D, const Work& wk, const cd (&c)[EPT]) {
+  // One tile into image D together with its mirror image; a tile ON the diagonal is replaced by its Hermitian part --
+  // inside the wavefront that computed it: raw store, transposed read, second store; LDS serves one wavefront's accesses in
+  // program order -- so the image is exactly Hermitian when the barrier after it opens, and c[] holds what was stored.
+  // Returns the tile's share of sum |delta_ij - D_ij|^2 over the WHOLE matrix (a mirrored element counts twice).
+  __device__ __forceinline__ static double store_hermitian_tile(cd* D, int row0, int col0, int r16, int kq, cd* c) {
+    const bool diag = col0 == row0;  // wave-uniform
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (t == 1 && !wk.two) break;
-      const int col0 = wk.col0 + 16 * t;
+    for (int r = 0; r < 4; ++r) {
+      const int i = row0 + kq + 4 * r, j = col0 + r16;
+      D[i * P + j] = c[r];
+      if (!diag) D[j * P + i] = cd{c[r].re, -c[r].im};
+    }
+    if (diag) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = wk.row0 + wk.kq + 4 * r, j = col0 + wk.r16;
-        D[i * P + j] = c[4 * t + r];
-        if (col0 != wk.row0) D[j * P + i] = cd{c[4 * t + r].re, -c[4 * t + r].im};
+        const cd ct = D[(col0 + r16) * P + row0 + kq + 4 * r];
+        c[r] = cd{0.5 * (c[r].re + ct.re), 0.5 * (c[r].im - ct.im)};
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D[(row0 + kq + 4 * r) * P + col0 + r16] = c[r];
     }
-  }
-  // The same for a product that is Hermitian up to rounding (Y = X X, Z = Y Y): a tile ON the diagonal is replaced by its
-  // Hermitian part -- inside the wavefront that computed it: raw store, transposed read, second store; LDS serves one
-  // wavefront's accesses in program order -- so the image is exactly Hermitian when the barrier after it opens, and c[]
-  // holds what was stored.  Returns this wavefront's share of sum |delta_ij - D_ij|^2 over the WHOLE matrix (elements of
-  // an off-diagonal tile count twice: their mirror images).
-  __device__ __forceinline__ static double store_hermitian(cd* D, const Work& wk, cd (&c)[EPT]) {
     double rp = 0.0;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (t == 1 && !wk.two) break;
-      const int col0 = wk.col0 + 16 * t;
-      const bool diag = col0 == wk.row0;  // wave-uniform
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = wk.row0 + wk.kq + 4 * r, j = col0 + wk.r16;
-        D[i * P + j] = c[4 * t + r];
-        if (!diag) D[j * P + i] = cd{c[4 * t + r].re, -c[4 * t + r].im};
-      }
-      if (diag) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = wk.row0 + wk.kq + 4 * r, j = col0 + wk.r16;
-          const cd ct = D[j * P + i];
-          c[4 * t + r] = cd{0.5 * (c[4 * t + r].re + ct.re), 0.5 * (c[4 * t + r].im - ct.im)};
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) D[(wk.row0 + wk.kq + 4 * r) * P + col0 + wk.r16] = c[4 * t + r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = wk.row0 + wk.kq + 4 * r, j = col0 + wk.r16;
-        const double dr = (i == j ? 1.0 : 0.0) - c[4 * t + r].re, di = c[4 * t + r].im;
-        rp += (diag ? 1.0 : 2.0) * (dr * dr + di * di);
-      }
+    for (int r = 0; r < 4; ++r) {
+      const double dr = ((row0 + kq + 4 * r == col0 + r16) ? 1.0 : 0.0) - c[r].re, di = c[r].im;
+      rp += (diag ? 1.0 : 2.0) * (dr * dr + di * di);
     }
     return rp;
+  }
+
+  // D <- fin(A B) for a product that is Hermitian up to rounding; D may be A or B.  `fin(c, row0, col0)` turns the raw tile
+  // c[0..3] at (row0, col0) into what is stored (it may read the OLD contents of any image at the tile's own positions).
+  // Sequence: every wavefront computes its share; wavefronts 0, 2 leave their halves of the split tiles in `part`;
+  // BARRIER (the halves are visible, and every operand read of A and B is done -- so D may alias them); stores.  The
+  // caller's next barrier publishes D.  Returns this wavefront's share of ||I - D||_F^2.
+  template <class Fin>
+  __device__ __forceinline__ static double product(const cd* A, const cd* B, cd* D, const Work& wk, double* sm, Fin fin) {
+    cd c[EPT];
+    tiles(A, B, wk, c);
+    cd* part = reinterpret_cast<cd*>(sm + oPart) + (wk.wave >> 1) * 4 * 64 + (wk.kq * 16 + wk.r16);
+    if (wk.half && !wk.owner) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[r * 64] = c[4 + r];
+    }
+    __syncthreads();
+    fin(c, wk.row0, wk.col0);
+    double rs = store_hermitian_tile(D, wk.row0, wk.col0, wk.r16, wk.kq, c);
+    if (wk.owner) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const cd o = part[r * 64];
+        c[4 + r] = cd{c[4 + r].re + o.re, c[4 + r].im + o.im};
+      }
+      fin(c + 4, wk.hrow0, wk.hcol0);
+      rs += store_hermitian_tile(D, wk.hrow0, wk.hcol0, wk.r16, wk.kq, c + 4);
+    }
+    return rs;
   }
 
   // Hermitian completion from the lower triangle (LAPACK zheevd, uplo = 'L': what numpy.linalg.eigh reads)
@@ -286,10 +303,9 @@ struct Proc64 {
     // The quintic: the odd one with p(1) = 1, p'(1) = -1/2 (lifted eigenvalues settle on 1 geometrically, so res ends up
     // measuring the stragglers only) and slope 3 at 0; slope 3.2 is where the invariant interval [0, 1.26] is lost.  It
     // grows an unlifted eigenvalue by 3.0 for 9 tile products where 1.9 x - 0.9 x^3 (round 2) took 6 for 1.9.
+    auto keep = [](cd*, int, int) {};
     for (int k = 0; k < 64; ++k) {  // every exit condition is workgroup-uniform (identical bits in every thread)
-      cd pr[EPT];
-      tile_product(X, X, wk, pr);
-      double rs = store_hermitian(Y, wk, pr);  // (image 1 is idle: the last product ended behind a barrier)
+      double rs = product(X, X, Y, wk, sm, keep);  // (image 1 is idle: the last product ended behind a barrier)
       rs = gsum<64>(rs);
       if ((m.tid & 63) == 0) red[wave] = rs;
       __syncthreads();
@@ -299,35 +315,24 @@ struct Proc64 {
       if (lifting && (res < 0.5 || k >= 24)) lifting = false;  // (3^24 = 2.8e11: what is still unlifted then is below 1e-11 ||A||)
       const bool last = !lifting && (res < 1e-14 || --ns_left <= 0);
       double alpha = 1.5, beta = -0.5;
-      if (lifting) {  // uniform
-        cd pz[EPT];
-        tile_product(Y, Y, wk, pz);
-        __syncthreads();  // every wavefront has read Y
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {  // (Y's own tile re-read: cheaper than 16 registers alive through the product)
-          if (t == 1 && !wk.two) break;
+      if (lifting) {  // uniform.  W' = -3.25 Y + 1.25 Y Y over Y (its own tile re-read: cheaper than registers kept alive)
+        (void)product(Y, Y, Y, wk, sm, [&](cd* c, int row0, int col0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const cd y = Y[(wk.row0 + wk.kq + 4 * r) * P + wk.col0 + 16 * t + wk.r16];
-            pz[4 * t + r] = cd{fma(1.25, pz[4 * t + r].re, -3.25 * y.re), fma(1.25, pz[4 * t + r].im, -3.25 * y.im)};
+            const cd y = Y[(row0 + wk.kq + 4 * r) * P + col0 + wk.r16];
+            c[r] = cd{fma(1.25, c[r].re, -3.25 * y.re), fma(1.25, c[r].im, -3.25 * y.im)};
           }
-        }
-        (void)store_hermitian(Y, wk, pz);  // W' (its diagonal tiles symmetrised like Y's)
+        });
         __syncthreads();
         alpha = 3.0, beta = 1.0;
       }
-      tile_product(X, Y, wk, pr);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (t == 1 && !wk.two) break;
+      (void)product(X, Y, X, wk, sm, [&](cd* c, int row0, int col0) {  // X <- alpha X + beta X Y (or X W')
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const cd x = X[(wk.row0 + wk.kq + 4 * r) * P + wk.col0 + 16 * t + wk.r16];
-          pr[4 * t + r] = cd{fma(beta, pr[4 * t + r].re, alpha * x.re), fma(beta, pr[4 * t + r].im, alpha * x.im)};
+          const cd x = X[(row0 + wk.kq + 4 * r) * P + col0 + wk.r16];
+          c[r] = cd{fma(beta, c[r].re, alpha * x.re), fma(beta, c[r].im, alpha * x.im)};
         }
-      }
-      __syncthreads();  // every wavefront has read X and Y
-      (void)store_hermitian(X, wk, pr);
+      });
       __syncthreads();
       ++steps;
       if (last || !(res == res)) break;
@@ -342,12 +347,7 @@ struct Proc64 {
       Y[e[r]] = a[r];
     }
     __syncthreads();
-    {
-      cd pr[EPT];
-      tile_product(Y, X, wk, pr);  // A S, Hermitian as well (A and its sign commute)
-      __syncthreads();             // the product's reads of image 1 are done
-      store_tiles(Y, wk, pr);
-    }
+    (void)product(Y, X, Y, wk, sm, keep);  // A S over A, Hermitian as well (A and its sign commute)
     __syncthreads();
     cd out[EPT];
 #pragma unroll

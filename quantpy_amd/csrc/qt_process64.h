@@ -765,6 +765,110 @@ struct Pgdb64 {
   }
 };
 
+// The model p = Re(V_S (X V_P^T)) and the NLL -sum n log|p + 1e-12| of ONE Choi matrix on the matrix cores, tiled over the
+// POVM rows (round 3): workgroup (c, tile) takes the 16 columns m0 .. m0 + 15 of p -- both products of a column tile are
+// independent of the other tiles -- and leaves its share of the NLL in fpart[c][tile]; the caller sums the tiles in order.
+// Pgdb64::forward runs the same two products as scalar loops in ONE workgroup: 0.7 ms of the 0.9 ms of a chain step.
+//   stage 1  Y[alpha][m] = sum_beta X[alpha][beta] V_P[m][beta]      wavefront w: rows 16 w .. 16 w + 15; three real products
+//   stage 2  p[s][m]     = Re sum_alpha V_S[s][alpha] Y[alpha][m]    wavefront w: states 16 w ..; the B operand of k-step k
+//            is accumulator element k % 4 of wavefront k / 4 at the SAME lane: Y passes through LDS as [wave][r][lane]
+struct Fwd64 {
+  static constexpr int DC = 64, P = DC + 1;
+  static constexpr int oX = 0, oY = 2 * DC * P, oRed = oY + 2 * 4 * 4 * 64, kDoubles = oRed + 8;
+  static constexpr size_t kLdsBytes = (size_t)kDoubles * sizeof(double);
+  __host__ __device__ static int tiles(int M) { return (M + 15) / 16; }
+};
+
+__global__ void __launch_bounds__(256) k_fwd64_nll(const int64_t* __restrict__ counts, int C, int M,
+                                                   const double* __restrict__ vs, const double* __restrict__ vp,
+                                                   const double* __restrict__ choi_a, const double* __restrict__ choi_b,
+                                                   int use_b, double* __restrict__ fpart) {
+  extern __shared__ __attribute__((aligned(16))) double smf[];
+  const int nt = Fwd64::tiles(M), c = blockIdx.x / nt, tile = blockIdx.x % nt;
+  if (c >= C) return;
+  constexpr int DC = Fwd64::DC, P = Fwd64::P;
+  cd* X = reinterpret_cast<cd*>(smf + Fwd64::oX);
+  cd* yl = reinterpret_cast<cd*>(smf + Fwd64::oY);
+  double* red = smf + Fwd64::oRed;
+  const cd* src = reinterpret_cast<const cd*>(use_b ? choi_b : choi_a) + (size_t)c * DC * DC;
+  Pgdb64::load_x(src, X);
+  __syncthreads();
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+  const int m0 = tile * 16, mrow = (m0 + r16 < M) ? m0 + r16 : M - 1;  // (columns past M: a valid row, ignored below)
+  const sc_v4f64 z = {0.0, 0.0, 0.0, 0.0};
+  {
+    sc_v4f64 p1 = z, p2 = z, p3 = z;
+    const cd* ap = X + (16 * w + r16) * P + kq;
+    const cd* bp = reinterpret_cast<const cd*>(vp) + (size_t)mrow * DC + kq;
+#pragma unroll
+    for (int k = 0; k < DC / 4; ++k) {
+      const cd a = ap[4 * k], b = bp[4 * k];
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, p1, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.im, p2, 0, 0, 0);
+      p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, b.re + b.im, p3, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yl[(w * 4 + r) * 64 + lane] = cd{p1[r] - p2[r], p3[r] - p1[r] - p2[r]};
+  }
+  __syncthreads();
+  sc_v4f64 q0 = z, q1 = z;
+  {
+    const cd* ap = reinterpret_cast<const cd*>(vs) + (size_t)(16 * w + r16) * DC + kq;
+#pragma unroll
+    for (int k = 0; k < DC / 4; ++k) {
+      const cd a = ap[4 * k], y = yl[k * 64 + lane];  // (k = 4 wave + r: element r of wavefront `wave`)
+      q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, y.re, q0, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, y.im, q1, 0, 0, 0);
+    }
+  }
+  const int64_t* cnt = counts + (size_t)c * DC * M;
+  double part = 0.0;
+  if (m0 + r16 < M) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int st = 16 * w + kq + 4 * r;
+      part += (double)cnt[(size_t)st * M + m0 + r16] * log(fabs((q0[r] + q1[r]) + 1e-12));
+    }
+  }
+  part = gsum<64>(part);
+  if (lane == 0) red[w] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) fpart[(size_t)c * nt + tile] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// the accept test of a chain step on the tiles' partial sums (k_mhmc64_accept's second half); t = -1: the starting point
+__global__ void __launch_bounds__(256) k_mhmc64_decide(int C, int nt, int T_steps, int t, const double* __restrict__ fpart,
+                                                       const double* __restrict__ proposal,
+                                                       const double* __restrict__ uniforms, double* __restrict__ x,
+                                                       double* __restrict__ fcur, double* __restrict__ chain_out,
+                                                       int32_t* __restrict__ accepted) {
+  const int c = blockIdx.x;
+  if (c >= C) return;
+  double sum = 0.0;
+  for (int k = 0; k < nt; ++k) sum += fpart[(size_t)c * nt + k];  // the same order in every thread
+  const double fn = -sum;
+  if (t < 0) {
+    if (threadIdx.x == 0) fcur[c] = fn;
+    return;
+  }
+  using S = Pgdb64;
+  cd* cur = reinterpret_cast<cd*>(x) + (size_t)c * S::NE;
+  const cd* prop = reinterpret_cast<const cd*>(proposal) + (size_t)c * S::NE;
+  const double f = fcur[c];
+  const bool acc = uniforms[(size_t)c * T_steps + t] <= exp(f - fn);
+  cd* out = reinterpret_cast<cd*>(chain_out) + ((size_t)c * T_steps + t) * S::NE;
+  for (int k = threadIdx.x; k < S::NE; k += 256) {
+    const cd v = acc ? prop[k] : cur[k];
+    out[k] = v;
+    if (acc) cur[k] = v;
+  }
+  __syncthreads();  // (every thread has read fcur[c])
+  if (threadIdx.x == 0) {
+    if (acc) fcur[c] = fn;
+    accepted[(size_t)c * T_steps + t] = acc ? 1 : 0;
+  }
+}
+
 // state[b] = {iteration, stopped, NaN seen, -}
 __global__ void __launch_bounds__(256) k_pgdb64_init(int B, double* __restrict__ choi, int32_t* __restrict__ state,
                                                      int32_t* __restrict__ iters, int32_t* __restrict__ status,
@@ -891,9 +995,10 @@ __global__ void __launch_bounds__(Pgdb64::NT) k_pgdb64_step(const int64_t* __res
 
 // The Metropolis-Hastings chain of MHMCProcessInterval at n = 3 (interval.py:808-836; the arithmetic as k_mhmc_process
 // restates it for n <= 2): step t proposes x' = P_CPTP(x + step * delta_t) and accepts iff u_t <= exp(nll(x) - nll(x')),
-// nll = -sum n log|L x + 1e-12| with L applied through its factors (Pgdb64::forward).  Three launches per step --
-// k_mhmc64_propose, k_cptp_project64, k_mhmc64_accept -- with the chain's point and its NLL in global memory; nothing
-// returns to the host between steps.  t = -1 evaluates the NLL of the starting point.
+// nll = -sum n log|L x + 1e-12| with L applied through its factors.  Four launches per step -- k_mhmc64_propose,
+// k_cptp_project64, k_fwd64_nll (the model and the NLL, tiled over the POVM rows on the matrix cores), k_mhmc64_decide --
+// with the chain's point and its NLL in global memory; nothing returns to the host between steps.  t = -1 evaluates the NLL
+// of the starting point.
 __global__ void __launch_bounds__(256) k_mhmc64_propose(int C, int T_steps, int t, double step, const double* __restrict__ x,
                                                         const double* __restrict__ deltas, double* __restrict__ trial) {
   const int c = blockIdx.x;
@@ -904,49 +1009,6 @@ __global__ void __launch_bounds__(256) k_mhmc64_propose(int C, int T_steps, int 
   for (int k = threadIdx.x; k < Pgdb64::NE; k += 256) {
     const int row = k >> 6, col = k & 63;
     out[k] = cd{cur[k].re + step * dl[col * Pgdb64::DC + row], cur[k].im};  // delta is indexed like the column-stacked vector
-  }
-}
-
-__global__ void __launch_bounds__(Pgdb64::NT) k_mhmc64_accept(const int64_t* __restrict__ counts, int C, int M, int T_steps, int t,
-                                                             const double* __restrict__ vs, const double* __restrict__ vp,
-                                                             const double* __restrict__ proposal,
-                                                             const double* __restrict__ uniforms, double* __restrict__ x,
-                                                             double* __restrict__ fcur, double* __restrict__ ws,
-                                                             double* __restrict__ chain_out, int32_t* __restrict__ accepted) {
-  extern __shared__ __attribute__((aligned(16))) double smp[];
-  const int c = blockIdx.x;
-  if (c >= C) return;
-  using S = Pgdb64;
-  const int R = S::DC * M;
-  cd* X = reinterpret_cast<cd*>(smp);
-  double* red = smp + 2 * S::DC * S::P;
-  double* wsb = ws + (size_t)c * S::ws_doubles(M);
-  cd* Y = reinterpret_cast<cd*>(wsb);
-  double* p = wsb + (size_t)2 * S::DC * M;
-  cd* cur = reinterpret_cast<cd*>(x) + (size_t)c * S::NE;
-  const cd* prop = t < 0 ? cur : reinterpret_cast<const cd*>(proposal) + (size_t)c * S::NE;
-  S::load_x(prop, X);
-  S::forward(X, reinterpret_cast<const cd*>(vs), reinterpret_cast<const cd*>(vp), M, Y, p);
-  const int64_t* cnt = counts + (size_t)c * R;
-  double part = 0.0;
-  for (int r = threadIdx.x; r < R; r += S::NT) part += (double)cnt[r] * log(fabs(p[r] + 1e-12));
-  const double fn = -S::bsum(red, part);
-  if (t < 0) {
-    if (threadIdx.x == 0) fcur[c] = fn;
-    return;
-  }
-  const double f = fcur[c];
-  const bool acc = uniforms[(size_t)c * T_steps + t] <= exp(f - fn);
-  cd* out = reinterpret_cast<cd*>(chain_out) + ((size_t)c * T_steps + t) * S::NE;
-  for (int k = threadIdx.x; k < S::NE; k += S::NT) {
-    const cd v = acc ? prop[k] : cur[k];
-    out[k] = v;
-    if (acc) cur[k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (acc) fcur[c] = fn;
-    accepted[(size_t)c * T_steps + t] = acc ? 1 : 0;
   }
 }
 

@@ -1923,26 +1923,32 @@ int qt_mhmc_process(qt_handle_t* h, const int64_t* counts, int C, const double* 
   if (int r = stage_out(h, h->out1, accepted, (size_t)C * T, flags, &dacc)) return r;
   if (h->proc.factored) {  // n = 3: three launches per step, the chain's state stays on the device (qt_process64.h)
     using S = qt::Pgdb64;
-    HIPCHK(h->ws_x.ensure(((size_t)C * S::ws_doubles(M) + C) * sizeof(double)));
+    const int nt = qt::Fwd64::tiles(M);
+    HIPCHK(h->ws_x.ensure(((size_t)C * S::ws_doubles(M) + C + (size_t)C * nt) * sizeof(double)));
     HIPCHK(h->ws_g.ensure((size_t)C * ne * 2 * sizeof(double)));     // proposals before the projection
     HIPCHK(h->ws_f.ensure((size_t)C * ne * 2 * sizeof(double)));     // ... and after it
     HIPCHK(h->hess.ensure((size_t)C * ne * 2 * sizeof(double)));     // the chains' current points
     HIPCHK(h->proc_ws.ensure((size_t)C * qt::Proc64::kWsComplex * 2 * sizeof(double)));
     if (int r = allow_big_lds(qt::k_cptp_project64, qt::Proc64::kLdsBytes)) return r;
-    if (int r = allow_big_lds(qt::k_mhmc64_accept, S::kLdsBytes)) return r;
-    double *ws = h->ws_x.as<double>(), *fcur = ws + (size_t)C * S::ws_doubles(M), *x = h->hess.as<double>();
+    if (int r = allow_big_lds(qt::k_fwd64_nll, qt::Fwd64::kLdsBytes)) return r;
+    double *ws = h->ws_x.as<double>(), *fcur = ws + (size_t)C * S::ws_doubles(M), *fpart = fcur + C, *x = h->hess.as<double>();
     const double *vs = (const double*)h->proc.in_states, *vp = (const double*)h->proc.emats;
     HIPCHK(hipMemcpyAsync(x, dx, (size_t)C * ne * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    hipLaunchKernelGGL(qt::k_mhmc64_accept, dim3(C), dim3(S::NT), S::kLdsBytes, h->stream, dc, C, M, T, -1, vs, vp,
-                       (const double*)nullptr, du, x, fcur, ws, dch, dacc);
+    // the model and the NLL of a point: C x ceil(M / 16) workgroups on the matrix cores (k_fwd64_nll), then the accept test
+    hipLaunchKernelGGL(qt::k_fwd64_nll, dim3(C * nt), dim3(256), qt::Fwd64::kLdsBytes, h->stream, dc, C, M, vs, vp,
+                       (const double*)x, (const double*)nullptr, 0, fpart);
+    hipLaunchKernelGGL(qt::k_mhmc64_decide, dim3(C), dim3(256), 0, h->stream, C, nt, T, -1, (const double*)fpart,
+                       (const double*)nullptr, du, x, fcur, dch, dacc);
     for (int t = 0; t < T; ++t) {
       hipLaunchKernelGGL(qt::k_mhmc64_propose, dim3(C), dim3(256), 0, h->stream, C, T, t, step, (const double*)x, dd,
                          h->ws_g.as<double>());
       hipLaunchKernelGGL(qt::k_cptp_project64, dim3(C), dim3(qt::Proc64::NT), qt::Proc64::kLdsBytes, h->stream,
                          (const double*)h->ws_g.as<double>(), C, 0, 1000, 1e-12, h->ws_f.as<double>(), (int32_t*)nullptr,
                          (int32_t*)nullptr, h->proc_ws.as<double>());
-      hipLaunchKernelGGL(qt::k_mhmc64_accept, dim3(C), dim3(S::NT), S::kLdsBytes, h->stream, dc, C, M, T, t, vs, vp,
-                         (const double*)h->ws_f.as<double>(), du, x, fcur, ws, dch, dacc);
+      hipLaunchKernelGGL(qt::k_fwd64_nll, dim3(C * nt), dim3(256), qt::Fwd64::kLdsBytes, h->stream, dc, C, M, vs, vp,
+                         (const double*)x, (const double*)h->ws_f.as<double>(), 1, fpart);
+      hipLaunchKernelGGL(qt::k_mhmc64_decide, dim3(C), dim3(256), 0, h->stream, C, nt, T, t, (const double*)fpart,
+                         (const double*)h->ws_f.as<double>(), du, x, fcur, dch, dacc);
     }
     HIPCHK(hipGetLastError());
     if (int r = fetch_out(h, dch, chain, (size_t)C * T * ne * 2, flags)) return r;

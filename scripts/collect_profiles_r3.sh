@@ -33,6 +33,7 @@ timeout -k 10 600 python3 scripts/pgdb3_timing.py > $OUT/${TAG}_pgdb3_timing.txt
 timeout -k 10 300 python3 scripts/lifp16_stream_timing.py > $OUT/${TAG}_lifp16_stream_timing.txt 2>&1
 { timeout -k 10 300 python3 scripts/cp_hard_spectra.py; timeout -k 10 300 python3 scripts/cp_accuracy_probe.py; } > $OUT/${TAG}_cp_accuracy_n3.txt 2>&1
 timeout -k 10 600 python3 scripts/clip_accuracy_n5.py > $OUT/${TAG}_clip_accuracy_n5.txt 2>&1
+timeout -k 10 600 python3 scripts/cptp_sweep.py 96 > $OUT/${TAG}_cptp_sweep.txt 2>&1
 { timeout -k 10 300 python3 scripts/large_n_timing.py 5 256; timeout -k 10 300 python3 scripts/large_n_timing.py 5 2048; timeout -k 10 300 python3 scripts/large_n_timing.py 4 1024; } > $OUT/${TAG}_large_n_timing.txt 2>&1
 timeout -k 10 300 python3 scripts/moment_coverage_timing.py > $OUT/${TAG}_moment_coverage_timing.txt 2>&1
 timeout -k 10 300 python3 scripts/bootstrap_timing.py > $OUT/${TAG}_bootstrap_end_to_end.txt 2>&1

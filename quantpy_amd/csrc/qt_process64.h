@@ -570,8 +570,8 @@ __global__ void __launch_bounds__(256) k_lifp_kron_finish(const double* __restri
 //            16 w .. 16 w + 15, two accumulator tiles (re, im) x two chains, K = M in steps of 4.  The counts are the A
 //            operand as they come (int64 -> double in the load path), the normalisation by N_s = sum_m n[s][m]
 //            (process.py:285) is applied to the 8 results per lane instead of the M operands: 0 / 0 = NaN as there.
-//   stage 2  X[alpha][beta] = sum_s V_S^+[alpha][s] T[s][beta]   complex x complex (four real products, two chains
-//            each): T through a 17 KB LDS tile, V_S^+ straight from L2 (requested before stage 1 starts).
+//   stage 2  X[alpha][beta] = sum_s V_S^+[alpha][s] T[s][beta]   complex x complex (three real products, three chains):
+//            T through a 17 KB LDS tile, V_S^+ straight from L2 (requested when stage 1's count buffers are free).
 //   store    Choi[(a d + b)][(c d + e)] = X[(a d + c)][(e d + b)]: a lane's 16 bytes sit in 128-byte runs (e = t % 8).
 // `vp_perm` [4][M][32] is V_P^+ with the columns of each workgroup side by side (re x 16 | im x 16): k_vp_perm
 // (qt_process.h), once per set-up.  Measured at B = 64: k_lifp_freq + k_gemm + k_lifp_kron_finish took 14.7 + 32.9 + 40.9 us (the first product
@@ -580,21 +580,18 @@ __global__ void __launch_bounds__(256) k_lifp64(const int64_t* __restrict__ coun
                                                 const double* __restrict__ vp_perm, const double* __restrict__ vs_pinv,
                                                 double* __restrict__ choi, int32_t* __restrict__ status,
                                                 int32_t* __restrict__ iters) {
-  constexpr int DC = 64, PT = 17, CH = 6;  // CH k-steps are requested while the previous CH run through the matrix pipe
+  constexpr int DC = 64, PT = 17, CH = 9;  // k-steps per request; TWO requests are in flight while a third is consumed
   __shared__ cd tl[DC * PT];
   const int b = blockIdx.x >> 2, j = blockIdx.x & 3;
   if (b >= B) return;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
   const cd* vrow = reinterpret_cast<const cd*>(vs_pinv) + (size_t)(16 * w + r16) * DC + kq;
-  cd va[DC / 4];
-#pragma unroll
-  for (int k = 0; k < DC / 4; ++k) va[k] = vrow[4 * k];
   const int64_t* crow = counts + ((size_t)b * DC + 16 * w + r16) * M + kq;
   const double* bp = vp_perm + ((size_t)j * M + kq) * 32 + r16;
   const int KS = M >> 2;  // (the host sends M % 4 == 0 here)
   sc_v4f64 tre[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, tim[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-  long long a0[CH], a1[CH];  // (raw counts: converted when they are consumed, so that a request does not wait for its data)
-  double p0[CH], q0[CH], p1[CH], q1[CH];
+  long long a0[CH], a1[CH], a2[CH];  // (raw counts: converted when they are consumed, so that a request does not wait for its data)
+  double p0[CH], q0[CH], p1[CH], q1[CH], p2[CH], q2[CH];
   double rs = 0.0;
   auto request = [&](int k0, long long (&a)[CH], double (&p)[CH], double (&q)[CH]) {
 #pragma unroll
@@ -614,12 +611,17 @@ __global__ void __launch_bounds__(256) k_lifp64(const int64_t* __restrict__ coun
     }
   };
   const int nfull = KS / CH;  // (every condition below is uniform over the workgroup)
+  // (round 3b: with ONE request ahead a workgroup alone on its CU -- B = 64 -- waited for nine load round trips in sequence,
+  //  20 us per launch; two ahead through three register buffers)
   if (nfull > 0) request(0, a0, p0, q0);
-  for (int c = 0; c < nfull; c += 2) {
-    if (c + 1 < nfull) request((c + 1) * CH, a1, p1, q1);
+  if (nfull > 1) request(CH, a1, p1, q1);
+  for (int c = 0; c < nfull; c += 3) {
+    if (c + 2 < nfull) request((c + 2) * CH, a2, p2, q2);
     consume(a0, p0, q0);
-    if (c + 2 < nfull) request((c + 2) * CH, a0, p0, q0);
+    if (c + 3 < nfull) request((c + 3) * CH, a0, p0, q0);
     if (c + 1 < nfull) consume(a1, p1, q1);
+    if (c + 4 < nfull) request((c + 4) * CH, a1, p1, q1);
+    if (c + 2 < nfull) consume(a2, p2, q2);
   }
   for (int k = nfull * CH; k < KS; ++k) {  // M / 4 not a multiple of CH: the last k-steps one at a time
     const double n = (double)crow[4 * k];
@@ -627,6 +629,9 @@ __global__ void __launch_bounds__(256) k_lifp64(const int64_t* __restrict__ coun
     tre[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(n, bp[(size_t)k * 128], tre[0], 0, 0, 0);
     tim[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(n, bp[(size_t)k * 128 + 16], tim[0], 0, 0, 0);
   }
+  cd va[DC / 4];  // (the second product's A operand, requested now that the count buffers are free: 64 registers)
+#pragma unroll
+  for (int k = 0; k < DC / 4; ++k) va[k] = vrow[4 * k];
   rs += __shfl_xor(rs, 16);
   rs += __shfl_xor(rs, 32);  // N_s of state 16 w + r16 (a sum of integers: exact in any order)
 #pragma unroll
@@ -636,14 +641,15 @@ __global__ void __launch_bounds__(256) k_lifp64(const int64_t* __restrict__ coun
     tl[(16 * w + row) * PT + r16] = cd{(tre[0][r] + tre[1][r]) / tot, (tim[0][r] + tim[1][r]) / tot};
   }
   __syncthreads();
-  sc_v4f64 xre[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, xim[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  // (three real products per complex one, as in the CP step: 48 instead of 64 matrix instructions per wavefront)
+  const sc_v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+  sc_v4f64 x1 = z4, x2 = z4, x3 = z4;
 #pragma unroll
   for (int k = 0; k < DC / 4; ++k) {
     const cd a = va[k], t = tl[(4 * k + kq) * PT + r16];
-    xre[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, t.re, xre[k & 1], 0, 0, 0);
-    xim[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, t.im, xim[k & 1], 0, 0, 0);
-    xre[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, t.im, xre[k & 1], 0, 0, 0);
-    xim[k & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, t.re, xim[k & 1], 0, 0, 0);
+    x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, t.re, x1, 0, 0, 0);
+    x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, t.im, x2, 0, 0, 0);
+    x3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, t.re + t.im, x3, 0, 0, 0);
   }
   cd* out = reinterpret_cast<cd*>(choi) + (size_t)b * DC * DC;
   const int e = r16 & 7, bb = 2 * j + (r16 >> 3);
@@ -651,7 +657,7 @@ __global__ void __launch_bounds__(256) k_lifp64(const int64_t* __restrict__ coun
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int alpha = 16 * w + kq + 4 * r, a = alpha >> 3, c = alpha & 7;
-    const cd x{xre[0][r] + xre[1][r], xim[0][r] + xim[1][r]};
+    const cd x{x1[r] - x2[r], x3[r] - x1[r] - x2[r]};
     out[(a * 8 + bb) * DC + c * 8 + e] = x;
     nan = nan || !(x.re == x.re);
   }
